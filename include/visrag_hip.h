@@ -1,0 +1,173 @@
+/*
+ * visrag_hip.h — C ABI of libvisrag_hip.so: the MI355X (gfx950) native VisRAG-Ret
+ * corpus-embedding + retrieval hot path.
+ *
+ * The reference (OpenBMB/VisRAG) has NO FFI for this path — it is pure Python over
+ * PyTorch ops — so this header is new surface.  Each entry point states the reference
+ * interface (file:line under /root/reference) whose device math it replaces; the Python
+ * adapter in visrag_amd/ keeps the reference's operator API on top of it
+ * (INTEGRATION.md shows the ctypes binding a maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; vr_last_error() gives text
+ *     (reference convention is Python exceptions: dense_retriever.py:70-71,
+ *      inference.py:105-108 — the adapter raises RuntimeError from the status).
+ *   - plain pointers and sizes only; no torch types.  "dev" pointers are HIP device
+ *     pointers (e.g. tensor.data_ptr() of a torch-ROCm tensor used as a container).
+ *   - the library owns device weights, workspace and the HBM-resident index; the caller
+ *     owns every input and output buffer.  No cross-boundary frees.
+ *   - a handle is NOT thread-safe: one handle per process / GPU (the reference runs one
+ *     process per GPU under torchrun, eval.sh:48).  `stream` is a hipStream_t (NULL = the
+ *     default stream) so torch containers stay ordered with the kernels.
+ */
+#ifndef VISRAG_HIP_H
+#define VISRAG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_OK 0
+#define VR_ERR_INVALID 1   /* bad argument / shape / missing weight */
+#define VR_ERR_HIP 2       /* HIP runtime failure */
+#define VR_ERR_STATE 3     /* call order (e.g. encode before weights are finalised) */
+#define VR_ERR_CAPACITY 4  /* workspace / index capacity exceeded */
+
+#define VR_DTYPE_F32 0
+#define VR_DTYPE_BF16 1
+
+typedef struct vr_model_s* vr_model_t;
+typedef struct vr_index_s* vr_index_t;
+
+/* Model dimensions (visrag_amd/config.py; SURVEY.md section 8 "dimension provenance"). */
+typedef struct vr_config {
+    int32_t patch_size;        /* 14 */
+    int32_t vit_dim;           /* 1152 */
+    int32_t vit_depth;         /* 26 (27 in the checkpoint, last dropped: modeling_minicpmv.py:70-71) */
+    int32_t vit_heads;         /* 16  -> head_dim must be 72 */
+    int32_t vit_hidden;        /* 4304 = int(1152*3.7362) */
+    int32_t vit_pos_grid;      /* 27  (learned pos-embed is 27x27) */
+    float   vit_ln_eps;        /* 1e-6 */
+    int32_t query_num;         /* 64 */
+    float   resampler_ln_eps;  /* 1e-6 */
+    int32_t hidden_size;       /* 2304 -> resampler heads = hidden/128, head_dim 128 */
+    int32_t num_layers;        /* 40 */
+    int32_t num_heads;         /* 36  -> head_dim must be 64 */
+    int32_t intermediate_size; /* 5760 */
+    int32_t vocab_size;        /* 122753 */
+    float   rms_norm_eps;      /* 1e-5 */
+    float   rope_theta;        /* 1e4 */
+    float   scale_emb;         /* 12 */
+    float   residual_scale;    /* scale_depth / sqrt(num_layers) = 1.4/sqrt(40) */
+    int32_t max_images;        /* workspace: image slices per ViT pass (chunk size) */
+    int32_t max_patches;       /* workspace: patches per image slice (1024 for 448x448; <=1064 sliced) */
+    int32_t max_tokens;        /* workspace: packed decoder tokens per vr_encode call */
+    int32_t max_seqs;          /* workspace: sequences per vr_encode call */
+} vr_config_t;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char* vr_version(void);
+/* Last error text of this thread's most recent failing call. */
+const char* vr_last_error(void);
+int vr_device_count(int* count);
+
+/* ---- model: replaces VisRAG_Ret.forward + pooling ----------------------------------- */
+/* Reference: DRModelForInference.build / from_pretrained
+ * (src/openmatch/modeling/dense_retrieval_model.py:233-364). */
+int vr_model_create(int device_id, const vr_config_t* cfg, vr_model_t* out);
+int vr_model_destroy(vr_model_t m);
+
+/* Load one tensor of the HF state dict by its key (e.g.
+ * "vpm.blocks.3.attn.qkv.weight", "resampler.proj", "llm.model.layers.7.mlp.up_proj.weight").
+ * `data` is row-major with `shape[ndim]`; dtype VR_DTYPE_F32 or VR_DTYPE_BF16; on_device
+ * tells whether `data` is a device pointer.  Unused keys (llm.lm_head.*, vpm.attn_pool.*,
+ * vpm.blocks.<depth>.*, resampler.pos_embed, rotary buffers) are accepted and ignored.
+ * Reference: PreTrainedModel.from_pretrained via dense_retrieval_model.py:292-318. */
+int vr_model_load_weight(vr_model_t m, const char* name, const void* data,
+                         const int64_t* shape, int32_t ndim, int32_t dtype, int32_t on_device);
+/* Check that every required weight arrived and build derived tables (packed / padded
+ * bf16 weights, resampler query projection, RoPE table). */
+int vr_model_finalize(vr_model_t m);
+
+/* Encode a batch of items (pages and/or text queries) to unit-norm embeddings.
+ *   slices      n_slices pointers to uint8 HWC (RGB) images, all on host or all on device
+ *   slice_hw    [n_slices][2] = (H, W), multiples of patch_size
+ *   input_ids   [T] packed token ids of all B items (already truncated to max_inp_length)
+ *   seq_offsets [B+1] token offsets of the items in `input_ids` (seq_offsets[B] == T)
+ *   vision_rows [n_slices*query_num] packed-token row that receives resampler output
+ *               (slice s, query j), or -1 to drop it (the reference's scatter_ of image_bound)
+ *   out_reps    [B][hidden_size] float32, device or host
+ * Replaces: VisRAG_Ret.forward (modeling_visrag_ret.py:86-126) incl. ToTensor/Normalize
+ * (modeling_minicpmv.py:84-92), get_vllm_embedding / get_vision_embedding (:95-171),
+ * timm forward_features (vision_transformer.py:682-692), Resampler.forward
+ * (resampler.py:146-168), MiniCPMModel.forward (modeling_minicpm.py:1147-1304), and the
+ * wmean pooling + F.normalize of DRModel.encode (dense_retrieval_model.py:180-184,222-223). */
+int vr_encode(vr_model_t m,
+              const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
+              int32_t slices_on_device,
+              const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
+              const int32_t* vision_rows,
+              float* out_reps, int32_t out_on_device, void* stream);
+
+/* Debug taps for parity tests: copy an internal activation of the LAST vr_encode call to
+ * host float32.  name in {"vit_embed","vit_block0","vit_out","resampler_out",
+ * "inputs_embeds","dec_layer0","last_hidden"}; rows/cols describe `out`. */
+int vr_model_tap(vr_model_t m, const char* name, float* out, int64_t rows, int64_t cols);
+/* Enable/disable recording of taps (off by default; costs device copies). */
+int vr_model_set_taps(vr_model_t m, int32_t enable);
+
+/* ---- index: replaces torch.matmul + torch.topk over pickle shards -------------------- */
+/* Reference: _retrieve_one_shard / distributed_parallel_retrieve
+ * (src/openmatch/retriever/dense_retriever.py:13-97); demo answer.py:26-35. */
+int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_index_t* out);
+int vr_index_destroy(vr_index_t ix);
+int vr_index_reset(vr_index_t ix);
+/* Append n rows of float32 [n][dim] (host or device); rows keep their insertion order,
+ * the global id of a row is its position. */
+int vr_index_add(vr_index_t ix, const float* reps, int64_t n, int32_t on_device, void* stream);
+int vr_index_size(vr_index_t ix, int64_t* n);
+/* For every query the k best rows by inner product: higher score first, lower row id first
+ * among equal scores.  Scores are exact fp32 dot products of the fp32 rows (a bf16 MFMA
+ * sweep selects candidates, the survivors are re-scored in fp32).
+ *   queries [nq][dim] float32;  out_scores [nq][k] float32;  out_ids [nq][k] int64
+ * (all host or all device per `on_device`).  If the index holds fewer than k rows the
+ * tail is filled with score -inf, id -1. */
+int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k,
+                    float* out_scores, int64_t* out_ids, int32_t on_device, void* stream);
+/* Merge per-shard results (e.g. after an RCCL all-gather): in [n_parts][nq][k] scores and
+ * global ids -> out [nq][k], same ordering rule.  Device pointers. */
+int vr_topk_merge(int device_id, const float* scores, const int64_t* ids, int32_t n_parts,
+                  int32_t nq, int32_t k, float* out_scores, int64_t* out_ids, void* stream);
+
+/* ---- single kernels (parity tests and micro-benchmarks call these through the ABI) ---- */
+/* out[M][N] = epilogue(A[M][K] * W[N][K]^T).  A, W bf16 row-major, K % 64 == 0,
+ * N % 128 == 0, buffers padded to a multiple of 128 rows.  epilogue:
+ *   0 bf16 out = acc + bias            3 f32 out = resid + alpha*(acc + bias)
+ *   1 bf16 out = gelu_erf(acc + bias)  4 bf16 out[N/2] = silu(gate)*up (16-row interleaved W)
+ *   2 f32  out = acc + bias            5 bf16 out = rope(acc) for col < rope_cols (head 64)
+ * bias (f32[N]) and resid (f32[M][ldo]) may be NULL. */
+int vr_op_gemm(int device_id, const void* A, int32_t lda, const void* W, int32_t ldw,
+               int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* bias,
+               const float* resid, float alpha, void* out, int32_t ldo,
+               const int32_t* rope_pos, const float* rope_table, int32_t rope_cols,
+               int32_t variant, void* stream);
+/* y = LN(x) (kind 0, affine, eps) or RMSNorm(x) (kind 1): x f32 [rows][dim] -> bf16 [rows][ldo]. */
+int vr_op_norm(int device_id, int32_t kind, const float* x, int32_t rows, int32_t dim,
+               const float* weight, const float* bias, float eps, void* out, int32_t ldo,
+               void* stream);
+/* Flash attention over bf16 q/k/v with row strides ld*, per-batch row ranges cu_q/cu_kv
+ * ([B+1], device), head_dim in {64,72,128}; causal uses absolute positions within the
+ * sequence.  q_batch_stride==0 shares q across the batch (resampler). out bf16 [rows_q][ldo]. */
+int vr_op_attention(int device_id, const void* q, int32_t ldq, const void* k, int32_t ldk,
+                    const void* v, int32_t ldv, void* out, int32_t ldo,
+                    const int32_t* cu_q, const int32_t* cu_kv, int32_t B, int32_t heads,
+                    int32_t head_dim, int32_t max_q, int32_t causal, int32_t q_shared,
+                    float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISRAG_HIP_H */

@@ -1,0 +1,83 @@
+// Launcher prototypes of the gfx950 kernels (host side of libvisrag_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vr {
+
+// ---- GEMM (gemm.hip) ---------------------------------------------------------------------
+enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_SWIGLU = 4, EPI_ROPE = 5 };
+enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1 };
+
+struct GemmArgs {
+    const void* A; int lda;          // bf16 [M_pad][lda]
+    const void* W; int ldw;          // bf16 [N][ldw]   (nn.Linear layout: [out][in])
+    int M, N, K;                     // N % 128 == 0, K % 64 == 0
+    const float* bias;               // f32 [N] or null
+    const float* resid;              // f32 [M][ldo] (EPI_RESID)
+    float alpha;                     // EPI_RESID scale
+    void* out; int ldo;
+    const int* rowmap;               // optional: output row of input row m (-1 = drop)
+    const float* rowbias;            // optional: f32 [period][rowbias_ld], added for n < rowbias_cols
+    int rowbias_period, rowbias_ld, rowbias_cols;
+    const int* rope_pos;             // EPI_ROPE: position of row m
+    const float* rope_table;         // f32 [max_pos][64] = cos[32] | sin[32]
+    int rope_cols;                   // columns < rope_cols are rotated (q and k), rest copied (v)
+};
+hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
+
+// ---- norms (norm.hip) --------------------------------------------------------------------
+// x f32 [rows][dim] -> bf16 [rows][ldo]; columns [dim, ldo) are written as zero.
+hipError_t launch_layernorm(const float* x, int rows, int dim, const float* w, const float* b,
+                            float eps, void* out, int ldo, hipStream_t s);
+hipError_t launch_rmsnorm(const float* x, int rows, int dim, const float* w, float eps,
+                          void* out, int ldo, hipStream_t s);
+
+// ---- attention (attention.hip) -----------------------------------------------------------
+struct AttnArgs {
+    const void* q; int ldq;          // bf16, row stride in elements; head h at column h*head_dim
+    const void* k; int ldk;
+    const void* v; int ldv;
+    void* out; int ldo;              // bf16 [rows_q][ldo], head h at column h*head_dim
+    const int* cu_q;                 // [B+1] row ranges of q/out (ignored for q when q_shared)
+    const int* cu_kv;                // [B+1] row ranges of k/v
+    int B, heads, head_dim, max_q;
+    int causal, q_shared;            // q_shared: q rows [0,max_q) are the same for every batch item
+    float scale;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---- elementwise / gather / pooling (misc.hip) ---------------------------------------------
+// u8 HWC image -> normalised bf16 im2col rows [(img, py, px)][c*P*P + ky*P + kx], K padded with 0.
+hipError_t launch_im2col(const uint8_t* const* imgs, int n_imgs, int H, int W, int P, void* out,
+                         int ldo, hipStream_t s);
+// h[t][:] = table[ids[t]][:] * scale   (bf16 table -> f32 rows)
+hipError_t launch_embed_gather(const int* ids, int T, const void* table, int dim, float scale,
+                               float* out, hipStream_t s);
+// final RMSNorm + position-weighted mean pool + L2 normalise: one embedding per sequence.
+hipError_t launch_pool(const float* h, const int* seq_offsets, int B, int dim, const float* norm_w,
+                       float eps, float* out, float* tap_hidden, hipStream_t s);
+hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
+// split x (f32) into hi + lo bf16 parts (x ~= hi + lo to ~16 bits of mantissa)
+hipError_t launch_split_bf16(const float* in, void* hi, void* lo, size_t n, hipStream_t s);
+hipError_t launch_iota_pos(const int* seq_offsets, int B, int* pos, hipStream_t s);
+
+// ---- search (search.hip) -------------------------------------------------------------------
+struct SearchArgs {
+    const void* index_bf16;          // [n_docs_pad][dim] bf16
+    const float* index_f32;          // [n_docs][dim] f32
+    int64_t n_docs;
+    int dim;
+    const void* q_bf16;              // [nq_pad][dim] bf16
+    const float* q_f32;              // [nq][dim]
+    int nq, k;
+    float* cand_scores; int* cand_ids; int n_chunks;   // workspace [nq_pad][n_chunks][KP]
+    float* out_scores; int64_t* out_ids;               // [nq][k]
+};
+int search_kprime(int k);            // candidates kept per (query, chunk); 0 if k unsupported
+int search_num_chunks(int64_t n_docs, int nq);
+hipError_t launch_search(const SearchArgs& a, hipStream_t s);
+hipError_t launch_topk_merge(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
+                             float* out_scores, int64_t* out_ids, hipStream_t s);
+
+}  // namespace vr

@@ -1,0 +1,86 @@
+// Wavefront LayerNorm / RMSNorm: one 64-lane wave per row, the whole row held in registers,
+// fp32 statistics (two-pass mean / centred variance), bf16 output for the next MFMA GEMM.
+//   LayerNorm(eps=1e-6, affine): vision_transformer.py:142,155,465,525; resampler.py:111,129-131
+//   MiniCPMRMSNorm: modeling_minicpm.py:119-136 (fp32 mean-square, rsqrt(var+eps), * weight)
+// Roofline: HBM (reads 4 B, writes 2 B per element).
+#include "common.h"
+#include "kernels.h"
+
+namespace vr {
+
+constexpr int NORM_MAXV = 10;   // float4 per lane: rows up to 64*4*10 = 2560 columns
+
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int rows, int dim,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ b, float eps,
+                                                   bf16_t* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * dim);
+    f32x4 v[NORM_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RMS) s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        else s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    s = wave_sum(s);
+    float mu = 0.f, rstd;
+    if constexpr (RMS) {
+        rstd = rsqrtf(s / dim + eps);
+    } else {
+        mu = s / dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NORM_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mu; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd = 1.0f / sqrtf(q / dim + eps);
+    }
+    bf16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 ww = reinterpret_cast<const f32x4*>(w)[c];
+            f32x4 y = (v[i] - mu) * rstd * ww;
+            if constexpr (!RMS) y += reinterpret_cast<const f32x4*>(b)[c];
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(y[r]);
+            reinterpret_cast<bf16x4*>(orow)[c] = o;
+        } else if (c * 4 < ldo) {
+            reinterpret_cast<bf16x4*>(orow)[c] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* x, int rows, int dim, const float* w, const float* b,
+                            float eps, void* out, int ldo, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (dim % 4 || ldo % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, w, b, eps,
+                       (bf16_t*)out, ldo);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmsnorm(const float* x, int rows, int dim, const float* w, float eps, void* out,
+                          int ldo, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (dim % 4 || ldo % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, w,
+                       (const float*)nullptr, eps, (bf16_t*)out, ldo);
+    return hipGetLastError();
+}
+
+}  // namespace vr

@@ -1,0 +1,9 @@
+#pragma once
+#include <hip/hip_runtime.h>
+namespace vr {
+// dst[(r/blk)*blk_stride + blk_off + r%blk][c] = (transpose ? src[c][r] : src[r][c]) as bf16
+hipError_t launch_pack_weight(const void* src, int src_is_bf16, int rows, int cols, int src_ld,
+                              int transpose, void* dst, int dst_ld, int blk, int blk_stride, int blk_off,
+                              hipStream_t s);
+hipError_t launch_to_f32(const void* src, int src_is_bf16, float* dst, size_t n, hipStream_t s);
+}  // namespace vr

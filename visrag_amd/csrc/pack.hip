@@ -1,0 +1,52 @@
+// Weight-preparation kernels (run once at load time): dtype conversion + zero padding +
+// row re-mapping (q|k|v stacking, 16-row gate/up interleave for the SwiGLU epilogue, transpose
+// of resampler.proj which the reference applies as `x @ proj`, resampler.py:167).
+#include "common.h"
+#include "pack.h"
+
+namespace vr {
+
+template <typename SrcT>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const SrcT* __restrict__ src, int rows, int cols,
+                                                          int src_ld, int transpose, bf16_t* __restrict__ dst,
+                                                          int dst_ld, int blk, int blk_stride, int blk_off) {
+    // dst[map(r)][c] = transpose ? src[c][r] : src[r][c]
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const float v = transpose ? (float)src[(size_t)c * src_ld + r] : (float)src[(size_t)r * src_ld + c];
+        const int dr = (r / blk) * blk_stride + blk_off + (r % blk);
+        dst[(size_t)dr * dst_ld + c] = f2bf(v);
+    }
+}
+
+hipError_t launch_pack_weight(const void* src, int src_is_bf16, int rows, int cols, int src_ld,
+                              int transpose, void* dst, int dst_ld, int blk, int blk_stride, int blk_off,
+                              hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)min((size_t)4096, (n + 255) / 256);
+    if (src_is_bf16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, rows,
+                           cols, src_ld, transpose, (bf16_t*)dst, dst_ld, blk, blk_stride, blk_off);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, rows,
+                           cols, src_ld, transpose, (bf16_t*)dst, dst_ld, blk, blk_stride, blk_off);
+    return hipGetLastError();
+}
+
+template <typename SrcT>
+__global__ void to_f32_kernel(const SrcT* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dst[i] = (float)src[i];
+}
+
+hipError_t launch_to_f32(const void* src, int src_is_bf16, float* dst, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)min((size_t)4096, (n + 255) / 256);
+    if (src_is_bf16) hipLaunchKernelGGL(to_f32_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, dst, n);
+    else hipLaunchKernelGGL(to_f32_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, dst, n);
+    return hipGetLastError();
+}
+
+}  // namespace vr

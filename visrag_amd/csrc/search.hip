@@ -1,0 +1,300 @@
+// Fused similarity GEMM + wavefront bitonic top-k over the HBM-resident index.
+// Replaces torch.matmul(Q, C^T) + torch.topk (dense_retriever.py:28-30): the Nq x Nd score
+// matrix is never written.
+//
+//  sweep   one workgroup = (doc chunk, 128-query tile).  For every 128-doc tile of its chunk it
+//          runs the bf16 MFMA main loop of gemm_core.h (A = index rows, W = query rows) and
+//          filters the 128x128 scores in registers against a per-query running threshold kept
+//          in LDS; survivors are appended to a 64-entry per-query LDS buffer, and a buffer that
+//          passes 32 entries is compacted by ONE wave with a 64-lane bitonic sort on
+//          (score desc, doc id asc) keys — one candidate per lane, cross-lane exchange only.
+//          Result: the exact bf16-score top-KP of the chunk per query.
+//  merge   one wave per query: bitonic-merge the per-chunk lists to the global bf16 top-KP,
+//          re-score those KP rows against the fp32 index in fp32 (exact dot products), sort,
+//          emit the top k.  KP >= k + 6, so bf16 rounding (|err| ~ 6e-5 on unit vectors) cannot
+//          push a true top-k row out of the candidate set unless > 6 rows tie within it.
+// Block placement: the 8 query tiles of a chunk are consecutive on ONE XCD (b % 8 == chunk % 8)
+// so the index tile is fetched from HBM once and re-read from that XCD's L2.
+// Roofline: MFMA for Nq >~ 300 (2*Nq*Nd*D flop), HBM for small Nq (Nd*D*2 bytes per sweep).
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vr {
+
+constexpr int SRCH_CAP = 64;        // per-query LDS candidate buffer (one entry per lane)
+constexpr int SRCH_TRIG = 32;       // compact when a buffer holds more than this
+
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t o) {
+    const uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(u);
+}
+// sort key: larger key = better candidate (higher score, then LOWER id)
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t id) {
+    return ((uint64_t)f32_orderable(score) << 32) | (uint32_t)(~id);
+}
+constexpr uint64_t KEY_NONE = 0;    // below every real key (score -inf, id 0xffffffff -> ~ = 0 ...)
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = __shfl((uint32_t)v, src, 64);
+    const uint32_t hi = __shfl((uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// 64-lane bitonic sort, descending: lane 0 ends with the largest key.
+__device__ __forceinline__ uint64_t wave_bitonic_desc(uint64_t key, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint64_t other = shfl_xor_u64(key, j);
+            const bool desc = (lane & k) == 0;
+            const bool low = (lane & j) == 0;
+            const bool keep_max = (desc == low);
+            const uint64_t mx = key > other ? key : other, mn = key > other ? other : key;
+            key = keep_max ? mx : mn;
+        }
+    }
+    return key;
+}
+// top-64 of (sorted-desc `cur`) U (arbitrary `fresh`), sorted descending
+__device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fresh, int lane) {
+    fresh = wave_bitonic_desc(fresh, lane);
+    const uint64_t rev = shfl_u64(fresh, 63 - lane);
+    const uint64_t best = cur > rev ? cur : rev;      // bitonic sequence holding the top 64
+    return wave_bitonic_desc(best, lane);
+}
+
+struct SweepLds {
+    float thr[128];
+    int cnt[128];
+    uint64_t cand[128][SRCH_CAP];
+};
+constexpr int SWEEP_SMEM = GEMM_SMEM_BYTES + (int)sizeof(SweepLds);
+
+template <int KP>
+__global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SweepLds& L = *reinterpret_cast<SweepLds*>(smem + GEMM_SMEM_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+
+    const int b = blockIdx.x;
+    const int chunk = (b / (8 * q_tiles)) * 8 + (b & 7);
+    const int qt = (b >> 3) % q_tiles;
+    const int q0 = qt * 128;
+    const int n_tiles = (int)((p.n_docs + 127) / 128);
+    const int tile_lo = chunk * tiles_per_chunk;
+    const int tile_hi = min(n_tiles, tile_lo + tiles_per_chunk);
+
+    if (tid < 128) { L.thr[tid] = -INFINITY; L.cnt[tid] = 0; }
+    __syncthreads();
+
+    // one wave compacts the buffers of its 32 queries: sort, keep the best KP, raise thr
+    auto compact = [&](bool force) {
+        const int qn = wave * 32 + (lane & 31);
+        const int c_l = L.cnt[qn];
+        unsigned long long todo = __ballot((lane < 32) && (force ? c_l > 0 : c_l > SRCH_TRIG));
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int qq = wave * 32 + src;
+            const int c = __shfl(c_l, src, 64);
+            uint64_t key = (lane < c) ? L.cand[qq][lane] : KEY_NONE;
+            key = wave_bitonic_desc(key, lane);
+            if (lane < KP) L.cand[qq][lane] = key;
+            const int keep = min(c, KP);
+            if (lane == KP - 1 && c >= KP) L.thr[qq] = orderable_f32((uint32_t)(key >> 32));
+            if (lane == 0) L.cnt[qq] = keep;
+        }
+    };
+
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const int doc0 = tile * 128;
+        gemm_acc_t acc;
+        gemm_zero(acc);
+        gemm_mainloop<true>(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim,
+                            doc0, q0, p.dim, smem);
+        // thresholds of this lane's 16 queries (4 fragments x 4 consecutive columns)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int doc = doc0 + wm * 64 + i * 16 + fr;
+            bool any = false;
+            if (doc < p.n_docs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qn = wn * 64 + j * 16 + fq * 4;
+                    const f32x4 th = *reinterpret_cast<const f32x4*>(&L.thr[qn]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float s = acc[i][j][r];
+                        if (s >= th[r]) {
+                            const int pos = atomicAdd(&L.cnt[qn + r], 1);
+                            L.cand[qn + r][pos] = make_key(s, (uint32_t)doc);
+                            any = true;
+                        }
+                    }
+                }
+            }
+            if (__syncthreads_or(any)) {     // rare after warm-up: thresholds reject almost all
+                compact(false);
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    compact(true);
+    __syncthreads();
+    // emit [query][chunk][KP] (score, id); unused slots: -inf / -1
+    for (int e = tid; e < 128 * KP; e += 256) {
+        const int qq = e / KP, s = e % KP;
+        const size_t o = ((size_t)(q0 + qq) * p.n_chunks + chunk) * KP + s;
+        if (s < L.cnt[qq]) {
+            const uint64_t key = L.cand[qq][s];
+            p.cand_scores[o] = orderable_f32((uint32_t)(key >> 32));
+            p.cand_ids[o] = (int)(~(uint32_t)key);
+        } else {
+            p.cand_scores[o] = -INFINITY;
+            p.cand_ids[o] = -1;
+        }
+    }
+}
+
+constexpr int MERGE_MAXV = 10;
+
+template <int KP>
+__global__ __launch_bounds__(256) void search_merge_kernel(SearchArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;
+    const int total = p.n_chunks * KP;
+    const float* cs = p.cand_scores + (size_t)q * total;
+    const int* ci = p.cand_ids + (size_t)q * total;
+    uint64_t best = KEY_NONE;
+    for (int base = 0; base < total; base += 64) {
+        const int e = base + lane;
+        uint64_t key = KEY_NONE;
+        if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
+        best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
+    }
+    // fp32 re-scoring of the best KP candidates (lane c < KP owns candidate c)
+    const int nv = p.dim >> 2;
+    f32x4 qv[MERGE_MAXV];
+    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
+#pragma unroll
+    for (int i = 0; i < MERGE_MAXV; ++i) {
+        const int c = lane + i * 64;
+        qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    uint64_t exact = KEY_NONE;
+    for (int c = 0; c < KP; ++c) {
+        const uint64_t key = shfl_u64(best, c);
+        if (key == KEY_NONE) break;                      // wave-uniform
+        const uint32_t id = ~(uint32_t)key;
+        const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id * p.dim);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MERGE_MAXV; ++i) {
+            const int cc = lane + i * 64;
+            if (cc < nv) {
+                const f32x4 d = dr[cc];
+                s += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
+            }
+        }
+        s = wave_sum(s);
+        if (lane == c) exact = make_key(s, id);
+    }
+    exact = wave_bitonic_desc(exact, lane);
+    if (lane < p.k) {
+        const bool ok = exact != KEY_NONE;
+        p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(exact >> 32)) : -INFINITY;
+        p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)exact) : (int64_t)-1;
+    }
+}
+
+int search_kprime(int k) {
+    if (k <= 0) return 0;
+    if (k <= 10) return 16;
+    if (k <= 26) return 32;
+    return 0;
+}
+
+int search_num_chunks(int64_t n_docs, int nq) {
+    const int q_tiles = (nq + 127) / 128;
+    const int n_tiles = (int)((n_docs + 127) / 128);
+    int chunks = ((512 / q_tiles) + 7) / 8 * 8;          // ~2 workgroups per CU
+    if (chunks < 8) chunks = 8;
+    while (chunks > 8 && chunks > n_tiles) chunks -= 8;
+    return chunks;
+}
+
+template <int KP>
+static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
+    const int q_tiles = (a.nq + 127) / 128;
+    const int n_tiles = (int)((a.n_docs + 127) / 128);
+    const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
+    auto k = search_sweep_kernel<KP>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEP_SMEM); attr = true; }
+    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(search_merge_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
+    if (a.nq <= 0) return hipSuccess;
+    if (a.dim % 64 || a.dim > 64 * 4 * MERGE_MAXV || a.n_chunks % 8) return hipErrorInvalidValue;
+    switch (search_kprime(a.k)) {
+        case 16: return launch_kp<16>(a, s);
+        case 32: return launch_kp<32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---- multi-GPU: merge per-shard (score, global id) lists after the all-gather -----------------
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores,
+                                                         const int64_t* __restrict__ ids, int n_parts,
+                                                         int nq, int k, float* __restrict__ out_scores,
+                                                         int64_t* __restrict__ out_ids) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int total = n_parts * k;
+    uint64_t best = KEY_NONE;
+    for (int base = 0; base < total; base += 64) {
+        const int e = base + lane;
+        uint64_t key = KEY_NONE;
+        if (e < total) {
+            const int part = e / k, s = e % k;
+            const size_t o = ((size_t)part * nq + q) * k + s;
+            if (ids[o] >= 0) key = make_key(scores[o], (uint32_t)ids[o]);
+        }
+        best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
+    }
+    if (lane < k) {
+        const bool ok = best != KEY_NONE;
+        out_scores[(size_t)q * k + lane] = ok ? orderable_f32((uint32_t)(best >> 32)) : -INFINITY;
+        out_ids[(size_t)q * k + lane] = ok ? (int64_t)(~(uint32_t)best) : (int64_t)-1;
+    }
+}
+
+hipError_t launch_topk_merge(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
+                             float* out_scores, int64_t* out_ids, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    if (k > 64 || k <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, scores, ids, n_parts, nq, k,
+                       out_scores, out_ids);
+    return hipGetLastError();
+}
+
+}  // namespace vr
