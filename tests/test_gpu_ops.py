@@ -1,0 +1,167 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against an fp32 restatement of the same
+op on the same (bf16-rounded) inputs.  Tolerances are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import op_attention, op_gemm, op_norm  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale)
+
+
+# ------------------------------------------------------------------------------- GEMM ---
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1024, 384, 640), (77, 128, 2304)])
+def test_gemm_bias_bf16(M, N, K, variant):
+    A, W, b = _bf(_rand((M, K), 1)), _bf(_rand((N, K), 2, 0.1)), _rand((N,), 3)
+    ref = A.float() @ W.float().T + b
+    out = op_gemm(A.to(DEV), W.to(DEV), 0, bias=b.to(DEV), variant=variant).float().cpu()
+    # fp32 accumulate, one bf16 rounding of the output: |err| <= 2^-8 |ref| + accumulation noise
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
+    # transpose-detecting: asymmetric inputs, elementwise agreement much tighter than a swap
+    assert (out - ref).abs().max() < 0.05 * ref.abs().max()
+
+
+def test_gemm_identity_asymmetric():
+    """A = I (padded), asymmetric W: catches row/col swaps of the MFMA C layout."""
+    K = 128
+    A = torch.eye(K)[:100]
+    W = (torch.arange(256 * K).reshape(256, K) % 97).float() / 97.0 + torch.arange(256)[:, None] * 0.01
+    out = op_gemm(_bf(A).to(DEV), _bf(W).to(DEV), 2, out_dtype=torch.float32).cpu()
+    np.testing.assert_allclose(out.numpy(), _bf(W).float().T[:100].numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_epilogues(variant):
+    M, N, K = 200, 256, 128
+    A, W, b = _bf(_rand((M, K), 4)), _bf(_rand((N, K), 5, 0.2)), _rand((N,), 6)
+    acc = A.float() @ W.float().T
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    # 1: exact-erf GELU
+    out = op_gemm(Ad, Wd, 1, bias=bd, variant=variant).float().cpu()
+    np.testing.assert_allclose(out.numpy(), torch.nn.functional.gelu(acc + b).numpy(), rtol=1e-2, atol=2e-2)
+    # 2: fp32 out
+    out = op_gemm(Ad, Wd, 2, bias=bd, out_dtype=torch.float32, variant=variant).cpu()
+    np.testing.assert_allclose(out.numpy(), (acc + b).numpy(), rtol=1e-5, atol=1e-4)
+    # 3: residual with scale
+    r = _rand((M, N), 7)
+    out = op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.2214, out_dtype=torch.float32, variant=variant).cpu()
+    np.testing.assert_allclose(out.numpy(), (r + 0.2214 * (acc + b)).numpy(), rtol=1e-5, atol=1e-4)
+    # 4: SwiGLU with 16-row interleaved [gate|up] weights
+    I = N // 2
+    Wg, Wu = W[:I], W[I:]
+    Wi = torch.stack([Wg.reshape(I // 16, 16, K), Wu.reshape(I // 16, 16, K)], dim=1).reshape(N, K)
+    ref = torch.nn.functional.silu(A.float() @ Wg.float().T) * (A.float() @ Wu.float().T)
+    out = op_gemm(Ad, Wi.to(DEV), 4, out_cols=I, variant=variant).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
+
+
+def test_gemm_rope():
+    """EPI_ROPE == apply_rotary_pos_emb (modeling_minicpm.py:259-290) on q,k columns; v untouched."""
+    M, E, K = 150, 128, 128            # 2 heads of 64; N = 3E
+    A, W = _bf(_rand((M, K), 8)), _bf(_rand((3 * E, K), 9, 0.2))
+    pos = torch.arange(M, dtype=torch.int32) % 50
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
+    fr = torch.outer(torch.arange(64).float(), inv)
+    table = torch.cat([fr.cos(), fr.sin()], dim=1).contiguous()          # [pos][cos32|sin32]
+    acc = (A.float() @ W.float().T)
+    ref = acc.clone()
+    for part in range(2):                                                # q and k
+        for h in range(E // 64):
+            x = acc[:, part * E + h * 64: part * E + (h + 1) * 64]
+            c, s = fr.cos()[pos.long()], fr.sin()[pos.long()]
+            x1, x2 = x[:, :32], x[:, 32:]
+            ref[:, part * E + h * 64: part * E + h * 64 + 32] = x1 * c - x2 * s
+            ref[:, part * E + h * 64 + 32: part * E + (h + 1) * 64] = x2 * c + x1 * s
+    out = op_gemm(A.to(DEV), W.to(DEV), 5, rope_pos=pos.to(DEV), rope_table=table.to(DEV), rope_cols=2 * E).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
+
+
+# ------------------------------------------------------------------------------ norms ---
+@pytest.mark.parametrize("dim,ldo", [(1152, 1152), (2304, 2304), (288, 384)])
+def test_layernorm(dim, ldo):
+    x, w, b = _rand((37, dim), 10, 3.0) + 0.5, _rand((dim,), 11) * 0.2 + 1, _rand((dim,), 12) * 0.1
+    ref = torch.nn.functional.layer_norm(x, (dim,), w, b, 1e-6)
+    out = op_norm(0, x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, ldo).float().cpu()
+    np.testing.assert_allclose(out[:, :dim].numpy(), ref.numpy(), rtol=8e-3, atol=8e-3)   # bf16 output
+    assert (out[:, dim:] == 0).all()
+
+
+def test_rmsnorm():
+    dim = 2304
+    x, w = _rand((45, dim), 13, 2.0), _rand((dim,), 14) * 0.2 + 1
+    ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * w        # modeling_minicpm.py:119-123
+    out = op_norm(1, x.to(DEV), w.to(DEV), None, 1e-5).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=8e-3, atol=8e-3)
+
+
+# -------------------------------------------------------------------------- attention ---
+def _ref_attn(q, k, v, causal, scale):
+    s = (q.float() @ k.float().T) * scale
+    if causal:
+        L, Lk = s.shape
+        s = s + torch.full((L, Lk), float("-inf")).triu(1)
+    return torch.softmax(s, -1) @ v.float()
+
+
+@pytest.mark.parametrize("hd,heads,lens,causal", [
+    (72, 3, [64, 64], False), (72, 2, [1024], False), (72, 2, [1026, 60], False),
+    (64, 3, [68, 13, 130, 1], True), (64, 2, [700], True), (128, 2, [1024, 60], False)])
+def test_attention(hd, heads, lens, causal):
+    q_shared = hd == 128
+    B = len(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    T = int(cu[-1])
+    W = heads * hd
+    qkv = _bf(_rand((T, 3 * W), 20, 1.0))
+    scale = hd ** -0.5
+    if q_shared:
+        Qn = 64
+        qs = _bf(_rand((Qn, W), 21))
+        cu_q = torch.arange(B + 1, dtype=torch.int32) * Qn
+        out = op_attention(qs.to(DEV), qkv[:, W:2 * W].to(DEV), qkv[:, 2 * W:].to(DEV), cu_q.to(DEV), cu.to(DEV), heads,
+                           hd, Qn, False, True, scale, B * Qn).float().cpu()
+    else:
+        d = qkv.to(DEV)
+        out = op_attention(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], cu.to(DEV), cu.to(DEV), heads, hd, max(lens), causal,
+                           False, scale, T).float().cpu()
+    for b in range(B):
+        lo, hi = int(cu[b]), int(cu[b + 1])
+        for h in range(heads):
+            k = qkv[lo:hi, W + h * hd: W + (h + 1) * hd]
+            v = qkv[lo:hi, 2 * W + h * hd: 2 * W + (h + 1) * hd]
+            if q_shared:
+                ref = _ref_attn(qs[:, h * hd:(h + 1) * hd], k, v, False, scale)
+                got = out[b * 64:(b + 1) * 64, h * hd:(h + 1) * hd]
+            else:
+                ref = _ref_attn(qkv[lo:hi, h * hd:(h + 1) * hd], k, v, causal, scale)
+                got = out[lo:hi, h * hd:(h + 1) * hd]
+            # P and the output are rounded to bf16: 2^-8 relative on O(1) values
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+
+
+def test_attention_spiked_scores():
+    """Force the online-softmax rescale branch: one key dominates from a late tile."""
+    hd, heads, L = 64, 1, 300
+    q = _rand((L, hd), 30); k = _rand((L, hd), 31); v = _rand((L, hd), 32)
+    k[250] = q[10] * 8.0                                # huge logit for row 10 in the 4th tile
+    qkv = _bf(torch.cat([q, k, v], dim=1))
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    d = qkv.to(DEV)
+    out = op_attention(d[:, :hd], d[:, hd:2 * hd], d[:, 2 * hd:], cu.to(DEV), cu.to(DEV), 1, hd, L, False, False,
+                       hd ** -0.5, L).float().cpu()
+    ref = _ref_attn(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], False, hd ** -0.5)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)

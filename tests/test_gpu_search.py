@@ -1,0 +1,102 @@
+"""-m gpu: fused similarity + top-k (vr_index_*) against the oracle's fp32 matmul + top-k
+(oracle/visrag_ret_oracle.py::search_topk == dense_retriever.py:13-34 with a fixed tie rule).
+Bar: identical ids (bit-exact index work), scores within 1e-5 (fp32 dot, different summation
+order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import visrag_ret_oracle as O  # noqa: E402
+from visrag_amd.engine import HipIndex, topk_merge  # noqa: E402
+from visrag_amd.retriever import merge_topk_host  # noqa: E402
+
+
+def _unit(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("nd,nq,dim,k", [(5000, 37, 256, 10), (130, 3, 64, 5), (20000, 300, 2304, 10),
+                                          (1000, 130, 128, 20), (7, 2, 64, 10)])
+def test_search_matches_oracle(nd, nq, dim, k):
+    C, Q = _unit(nd, dim, 1), _unit(nq, dim, 2)
+    ix = HipIndex(dim, nd)
+    ix.add(C[: nd // 2]); ix.add(C[nd // 2:])
+    assert len(ix) == nd
+    sc, ids = ix.search(Q, k)
+    rs, ri = O.search_topk(Q, C, k)
+    kk = min(k, nd)
+    assert np.array_equal(ids[:, :kk], ri)
+    np.testing.assert_allclose(sc[:, :kk], rs, atol=1e-5, rtol=0)
+    if kk < k:
+        assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()
+
+
+def test_search_ties_and_duplicates():
+    """Duplicate rows tie exactly: lower row id must win, like the oracle's rule."""
+    dim = 128
+    C = _unit(2000, dim, 3)
+    C[1500:1540] = C[7]                       # 40 copies of row 7 -> more ties than candidates kept
+    C[900] = C[11]
+    Q = np.concatenate([C[7:8], C[11:12], _unit(5, dim, 4)])
+    ix = HipIndex(dim, 2000)
+    ix.add(C)
+    sc, ids = ix.search(Q, 10)
+    rs, ri = O.search_topk(Q, C, 10)
+    assert np.array_equal(ids, ri)
+    assert ids[0, 0] == 7 and list(ids[0, 1:]) == list(range(1500, 1509))
+    assert list(ids[1, :2]) == [11, 900]
+
+
+def test_search_golden_reference(golden_dir):
+    """Same corpus/queries as the REFERENCE run in tests/golden/retrieve.npz: the global top-5
+    must be the reference's (distributed_parallel_retrieve over 3 shards)."""
+    g = np.load(os.path.join(golden_dir, "retrieve.npz"))
+    ix = HipIndex(64, 600)
+    ix.add(g["C"])
+    sc, ids = ix.search(g["Q"], 5)
+    for qi in range(len(g["Q"])):
+        assert [f"doc{j}" for j in ids[qi]] == [str(d) for d in g["docs"][qi][:5]]
+        np.testing.assert_allclose(sc[qi], g["scores"][qi][:5], atol=1e-5)
+
+
+def test_search_device_tensors_and_sortedness():
+    """Full BASELINE size (100k x 2304, 1k queries): size-independent properties — scores
+    sorted, ids valid and unique, every score equals the exact fp32 dot of its row, and
+    agreement with a torch fp32 brute force on a query subset."""
+    nd, nq, dim, k = 100_000, 1000, 2304, 10
+    g = torch.Generator(device="cuda").manual_seed(0)
+    C = torch.randn((nd, dim), generator=g, device="cuda")
+    C = C / C.norm(dim=1, keepdim=True)
+    Q = torch.randn((nq, dim), generator=g, device="cuda")
+    Q = Q / Q.norm(dim=1, keepdim=True)
+    ix = HipIndex(dim, nd)
+    ix.add(C)
+    sc, ids = ix.search(Q, k)
+    torch.cuda.synchronize()
+    assert (sc[:, :-1] >= sc[:, 1:]).all()
+    assert (ids >= 0).all() and (ids < nd).all()
+    assert all(len(set(r.tolist())) == k for r in ids[:50].cpu())
+    exact = (Q[:, None, :] * C[ids]).sum(-1)
+    assert (exact - sc).abs().max() < 2e-6
+    ref = (Q[:64] @ C.T)
+    rv, ri = torch.topk(ref, k, dim=1)
+    assert torch.equal(ri, ids[:64]) or (rv - sc[:64]).abs().max() < 1e-6
+
+
+def test_topk_merge_matches_host_rule():
+    P, nq, k = 4, 33, 10
+    rng = np.random.default_rng(5)
+    sc = np.sort(rng.standard_normal((P, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    ids = rng.permutation(P * nq * k).reshape(P, nq, k).astype(np.int64)
+    sc[1, :, 3] = sc[0, :, 2]                 # cross-part ties
+    ids[2, 5, 7:] = -1; sc[2, 5, 7:] = -np.inf
+    ms, mi = topk_merge(torch.from_numpy(sc).cuda(), torch.from_numpy(ids).cuda())
+    hs, hi = merge_topk_host(sc, ids, k)
+    assert np.array_equal(mi.cpu().numpy(), hi)
+    np.testing.assert_array_equal(ms.cpu().numpy(), hs)

@@ -1,0 +1,1052 @@
+// Host side of libvisrag_hip.so: the C ABI of include/visrag_hip.h — device weight store,
+// workspace, per-grid tables, and the launch sequence of one VisRAG-Ret encode pass.
+// Reference call stack this replaces: SURVEY.md section 3.1 (modeling_visrag_ret.py:86-126 ->
+// modeling_minicpmv.py:95-171 -> vision_transformer.py:682-692 / resampler.py:146-168 ->
+// modeling_minicpm.py:1147-1304 -> dense_retrieval_model.py:180-184,222-223).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/visrag_hip.h"
+#include "kernels.h"
+#include "pack.h"
+
+using namespace vr;
+
+// ------------------------------------------------------------------------------ errors ---
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(VR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+#define VRCHK(expr)            \
+    do {                       \
+        int r_ = (expr);       \
+        if (r_ != VR_OK) return r_; \
+    } while (0)
+
+static inline int pad128(int x) { return (x + 127) / 128 * 128; }
+static inline int64_t pad128l(int64_t x) { return (x + 127) / 128 * 128; }
+
+extern "C" const char* vr_version(void) { return "visrag_hip 0.1.0 (gfx950)"; }
+extern "C" const char* vr_last_error(void) { return g_err.c_str(); }
+extern "C" int vr_device_count(int* count) {
+    if (!count) return fail(VR_ERR_INVALID, "count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return VR_OK;
+}
+
+// ------------------------------------------------------------------------- device bufs ---
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        free();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return fail(VR_ERR_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        bytes = n;
+        e = hipMemset(p, 0, n);
+        if (e != hipSuccess) return fail(VR_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+        return VR_OK;
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Linear {            // bf16 [n_pad][k_pad] (+ f32 bias [n_pad])
+    DevBuf w, b;
+    int n = 0, k = 0, n_pad = 0, k_pad = 0;
+    bool has_w = false, has_b = false;
+};
+struct Vec { DevBuf v; bool ok = false; };   // f32 vector (norm weights / biases)
+
+struct VitBlock { Vec n1w, n1b, n2w, n2b; Linear qkv, proj, fc1, fc2; };
+struct DecLayer { Vec ln1, ln2; Linear qkv, o, gu, down; int parts_qkv = 0, parts_gu = 0; };
+
+struct GridTables {
+    int gh = 0, gw = 0;
+    DevBuf vit_pos;        // f32 [N][Dp]  : bicubic-antialias resample of vpm.pos_embed
+    DevBuf pos_k;          // f32 [N][E]   : sincos2d(N,E) @ Wk^T (the k-side position term)
+};
+
+struct Tap { std::vector<float> data; int64_t rows = 0, cols = 0; };
+
+struct vr_model_s {
+    int device = 0;
+    vr_config_t c{};
+    bool finalized = false, taps_on = false;
+    // dims
+    int D = 0, Dp = 0, F = 0, Fp = 0, E = 0, I = 0, Ip = 0, Kpe = 0, Kpe_p = 0, Q = 0;
+    // weights
+    Linear patch;
+    std::vector<float> pos_embed_host;       // [G*G][D]
+    std::vector<VitBlock> blocks;
+    Vec vit_nw, vit_nb;
+    Linear r_kvproj, r_kv, r_out, r_proj;    // r_kv = in_proj rows [E,3E) (k|v)
+    Vec r_lnq_w, r_lnq_b, r_lnkv_w, r_lnkv_b, r_lnpost_w, r_lnpost_b;
+    std::vector<float> r_query_host, r_wq_host, r_bq_host;   // for the one-time q projection
+    bool has_query = false, has_inproj = false, has_inproj_b = false, has_pos = false;
+    DevBuf r_q;                               // bf16 [64][E] projected queries
+    DevBuf embed;  bool has_embed = false;    // bf16 [V][E]
+    std::vector<DecLayer> layers;
+    Vec final_norm;
+    DevBuf rope;                              // f32 [max_pos][64]
+    int rope_len = 0;
+    std::map<std::pair<int, int>, GridTables> grids;
+    // workspace
+    int64_t Mcap = 0, Tcap = 0, Rcap = 0;     // padded rows: patches, tokens, resampler rows
+    DevBuf w_im2col, w_hvit, w_xn, w_qkv, w_att, w_mlp, w_kv32, w_xkv, w_KV, w_ratt, w_rout, w_rln;
+    DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact;
+    DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
+    std::map<std::string, Tap> taps;
+    // pinned host arena for the small per-call arrays (ids, offsets, row maps, image pointers):
+    // async H2D copies read it after vr_encode returned, `arena_ev` marks when they have run.
+    char* arena = nullptr; size_t arena_cap = 0, arena_used = 0;
+    hipEvent_t arena_ev = nullptr; bool arena_pending = false;
+};
+
+static int arena_begin(vr_model_s* m, size_t need) {
+    if (m->arena_pending) { HIPCHK(hipEventSynchronize(m->arena_ev)); m->arena_pending = false; }
+    if (!m->arena_ev) HIPCHK(hipEventCreateWithFlags(&m->arena_ev, hipEventDisableTiming));
+    if (m->arena_cap < need) {
+        if (m->arena) (void)hipHostFree(m->arena);
+        m->arena = nullptr; m->arena_cap = 0;
+        const size_t cap = std::max(need, (size_t)4 << 20);
+        HIPCHK(hipHostMalloc((void**)&m->arena, cap, hipHostMallocDefault));
+        m->arena_cap = cap;
+    }
+    m->arena_used = 0;
+    return VR_OK;
+}
+static void* arena_take(vr_model_s* m, size_t bytes) {
+    void* p = m->arena + m->arena_used;
+    m->arena_used += (bytes + 63) / 64 * 64;
+    return p;
+}
+
+static int set_dev(int dev) {
+    HIPCHK(hipSetDevice(dev));
+    return VR_OK;
+}
+
+// ------------------------------------------------------------------------------ create ---
+extern "C" int vr_model_create(int device_id, const vr_config_t* cfg, vr_model_t* out) {
+    if (!cfg || !out) return fail(VR_ERR_INVALID, "cfg/out is NULL");
+    const vr_config_t& c = *cfg;
+    if (c.vit_dim % c.vit_heads || c.vit_dim / c.vit_heads != 72)
+        return fail(VR_ERR_INVALID, "ViT head_dim must be 72 (vit_dim %d / heads %d)", c.vit_dim, c.vit_heads);
+    if (c.hidden_size % 128) return fail(VR_ERR_INVALID, "hidden_size %d must be a multiple of 128", c.hidden_size);
+    if (c.hidden_size % c.num_heads || c.hidden_size / c.num_heads != 64)
+        return fail(VR_ERR_INVALID, "decoder head_dim must be 64");
+    if (c.intermediate_size % 64) return fail(VR_ERR_INVALID, "intermediate_size must be a multiple of 64");
+    if (c.query_num != 64) return fail(VR_ERR_INVALID, "query_num must be 64");
+    if (c.vit_dim % 4 || c.hidden_size > 2560 || c.vit_dim > 2560) return fail(VR_ERR_INVALID, "dims out of range");
+    if (c.max_images <= 0 || c.max_patches <= 0 || c.max_tokens <= 0 || c.max_seqs <= 0)
+        return fail(VR_ERR_INVALID, "workspace limits must be positive");
+    VRCHK(set_dev(device_id));
+    vr_model_s* m = new vr_model_s();
+    m->device = device_id;
+    m->c = c;
+    m->D = c.vit_dim; m->Dp = pad128(c.vit_dim);
+    m->F = c.vit_hidden; m->Fp = pad128(c.vit_hidden);
+    m->E = c.hidden_size; m->I = c.intermediate_size; m->Ip = pad128(c.intermediate_size);
+    m->Kpe = 3 * c.patch_size * c.patch_size; m->Kpe_p = pad128(m->Kpe);
+    m->Q = c.query_num;
+    m->blocks.resize(c.vit_depth);
+    m->layers.resize(c.num_layers);
+    *out = m;
+    return VR_OK;
+}
+
+extern "C" int vr_model_destroy(vr_model_t m) {
+    if (!m) return VR_OK;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    auto fl = [](Linear& l) { l.w.free(); l.b.free(); };
+    fl(m->patch); fl(m->r_kvproj); fl(m->r_kv); fl(m->r_out); fl(m->r_proj);
+    for (auto& b : m->blocks) { fl(b.qkv); fl(b.proj); fl(b.fc1); fl(b.fc2); b.n1w.v.free(); b.n1b.v.free(); b.n2w.v.free(); b.n2b.v.free(); }
+    for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); l.ln1.v.free(); l.ln2.v.free(); }
+    for (Vec* v : {&m->vit_nw, &m->vit_nb, &m->r_lnq_w, &m->r_lnq_b, &m->r_lnkv_w, &m->r_lnkv_b, &m->r_lnpost_w, &m->r_lnpost_b, &m->final_norm}) v->v.free();
+    for (auto& g : m->grids) { g.second.vit_pos.free(); g.second.pos_k.free(); }
+    if (m->arena) (void)hipHostFree(m->arena);
+    if (m->arena_ev) (void)hipEventDestroy(m->arena_ev);
+    for (DevBuf* b : {&m->r_q, &m->embed, &m->rope, &m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
+                      &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_dqkv,
+                      &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
+                      &m->w_pix, &m->w_out})
+        b->free();
+    delete m;
+    return VR_OK;
+}
+
+// ------------------------------------------------------------------------- weight load ---
+// Stage `data` (host or device, f32 or bf16) on the device; returns a device pointer that is
+// valid until the next call (tmp buffer) or `data` itself when it is already on the device.
+struct Staged { const void* dev = nullptr; DevBuf tmp; };
+
+static int stage(const void* data, size_t bytes, int on_device, Staged& st) {
+    if (on_device) { st.dev = data; return VR_OK; }
+    VRCHK(st.tmp.alloc(bytes));
+    HIPCHK(hipMemcpy(st.tmp.p, data, bytes, hipMemcpyHostToDevice));
+    st.dev = st.tmp.p;
+    return VR_OK;
+}
+
+// rows of a [n][k] weight go to rows (r/blk)*blk_stride + blk_off + r%blk of the padded dst
+static int load_linear_part(Linear& L, int n_total, int k, const void* dev_src, int is_bf16, int rows, int src_ld,
+                            int transpose, int blk, int blk_stride, int blk_off) {
+    if (!L.w.p) {
+        L.n = n_total; L.k = k; L.n_pad = pad128(n_total); L.k_pad = pad128(k);
+        VRCHK(L.w.alloc((size_t)L.n_pad * L.k_pad * 2));
+    } else if (L.n != n_total || L.k != k) {
+        return fail(VR_ERR_INVALID, "inconsistent shapes for a packed weight");
+    }
+    HIPCHK(launch_pack_weight(dev_src, is_bf16, rows, k, src_ld, transpose, L.w.p, L.k_pad, blk, blk_stride, blk_off, 0));
+    HIPCHK(hipDeviceSynchronize());
+    L.has_w = true;
+    return VR_OK;
+}
+
+static int load_bias_part(Linear& L, int n_total, const void* dev_src, int is_bf16, int rows, int off) {
+    if (!L.b.p) VRCHK(L.b.alloc((size_t)pad128(n_total) * 4));
+    HIPCHK(launch_to_f32(dev_src, is_bf16, L.b.as<float>() + off, rows, 0));
+    HIPCHK(hipDeviceSynchronize());
+    L.has_b = true;
+    return VR_OK;
+}
+
+static int load_vec(Vec& v, const void* dev_src, int is_bf16, int n, int n_alloc) {
+    VRCHK(v.v.alloc((size_t)n_alloc * 4));
+    HIPCHK(launch_to_f32(dev_src, is_bf16, v.v.as<float>(), n, 0));
+    HIPCHK(hipDeviceSynchronize());
+    v.ok = true;
+    return VR_OK;
+}
+
+static int to_host_f32(const void* dev_src, int is_bf16, size_t n, std::vector<float>& out) {
+    DevBuf t;
+    VRCHK(t.alloc(n * 4));
+    HIPCHK(launch_to_f32(dev_src, is_bf16, t.as<float>(), n, 0));
+    out.resize(n);
+    HIPCHK(hipMemcpy(out.data(), t.p, n * 4, hipMemcpyDeviceToHost));
+    t.free();
+    return VR_OK;
+}
+
+static bool shape_is(const int64_t* s, int nd, std::initializer_list<int64_t> want) {
+    if (nd != (int)want.size()) return false;
+    int i = 0;
+    for (int64_t w : want) if (s[i++] != w) return false;
+    return true;
+}
+
+extern "C" int vr_model_load_weight(vr_model_t m, const char* name_c, const void* data, const int64_t* shape,
+                                    int32_t ndim, int32_t dtype, int32_t on_device) {
+    if (!m || !name_c || !data || !shape) return fail(VR_ERR_INVALID, "NULL argument");
+    if (dtype != VR_DTYPE_F32 && dtype != VR_DTYPE_BF16) return fail(VR_ERR_INVALID, "bad dtype %d", dtype);
+    VRCHK(set_dev(m->device));
+    const std::string name(name_c);
+    const int bf = dtype == VR_DTYPE_BF16;
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    const vr_config_t& c = m->c;
+    const int D = m->D, F = m->F, E = m->E, I = m->I;
+    auto bad_shape = [&]() { return fail(VR_ERR_INVALID, "unexpected shape for %s", name_c); };
+
+    // keys the embedding path does not use
+    if (name.rfind("llm.lm_head.", 0) == 0 || name.rfind("vpm.attn_pool.", 0) == 0 ||
+        name == "resampler.pos_embed" || name.find("rotary_emb") != std::string::npos)
+        return VR_OK;
+
+    Staged st;
+    VRCHK(stage(data, numel * (bf ? 2 : 4), on_device, st));
+    const void* src = st.dev;
+    m->finalized = false;
+
+    if (name == "vpm.patch_embed.proj.weight") {
+        if (!shape_is(shape, ndim, {D, 3, c.patch_size, c.patch_size})) return bad_shape();
+        return load_linear_part(m->patch, D, m->Kpe, src, bf, D, m->Kpe, 0, D, 0, 0);
+    }
+    if (name == "vpm.patch_embed.proj.bias") { if (numel != (size_t)D) return bad_shape(); return load_bias_part(m->patch, D, src, bf, D, 0); }
+    if (name == "vpm.pos_embed") {
+        if (numel != (size_t)c.vit_pos_grid * c.vit_pos_grid * D) return bad_shape();
+        m->has_pos = true;
+        m->grids.clear();
+        return to_host_f32(src, bf, numel, m->pos_embed_host);
+    }
+    if (name == "vpm.norm.weight") { if (numel != (size_t)D) return bad_shape(); return load_vec(m->vit_nw, src, bf, D, m->Dp); }
+    if (name == "vpm.norm.bias") { if (numel != (size_t)D) return bad_shape(); return load_vec(m->vit_nb, src, bf, D, m->Dp); }
+    if (name.rfind("vpm.blocks.", 0) == 0) {
+        int n = -1, off = 0;
+        if (sscanf(name.c_str(), "vpm.blocks.%d.%n", &n, &off) < 1) return fail(VR_ERR_INVALID, "bad key %s", name_c);
+        if (n >= c.vit_depth) return VR_OK;     // dropped last block (modeling_minicpmv.py:70-71)
+        const std::string sub = name.substr(off);
+        VitBlock& b = m->blocks[n];
+        if (sub == "norm1.weight") { if (numel != (size_t)D) return bad_shape(); return load_vec(b.n1w, src, bf, D, m->Dp); }
+        if (sub == "norm1.bias") { if (numel != (size_t)D) return bad_shape(); return load_vec(b.n1b, src, bf, D, m->Dp); }
+        if (sub == "norm2.weight") { if (numel != (size_t)D) return bad_shape(); return load_vec(b.n2w, src, bf, D, m->Dp); }
+        if (sub == "norm2.bias") { if (numel != (size_t)D) return bad_shape(); return load_vec(b.n2b, src, bf, D, m->Dp); }
+        if (sub == "attn.qkv.weight") { if (!shape_is(shape, ndim, {3 * D, D})) return bad_shape(); return load_linear_part(b.qkv, 3 * D, D, src, bf, 3 * D, D, 0, 3 * D, 0, 0); }
+        if (sub == "attn.qkv.bias") { if (numel != (size_t)3 * D) return bad_shape(); return load_bias_part(b.qkv, 3 * D, src, bf, 3 * D, 0); }
+        if (sub == "attn.proj.weight") { if (!shape_is(shape, ndim, {D, D})) return bad_shape(); return load_linear_part(b.proj, D, D, src, bf, D, D, 0, D, 0, 0); }
+        if (sub == "attn.proj.bias") { if (numel != (size_t)D) return bad_shape(); return load_bias_part(b.proj, D, src, bf, D, 0); }
+        if (sub == "mlp.fc1.weight") { if (!shape_is(shape, ndim, {F, D})) return bad_shape(); return load_linear_part(b.fc1, F, D, src, bf, F, D, 0, F, 0, 0); }
+        if (sub == "mlp.fc1.bias") { if (numel != (size_t)F) return bad_shape(); return load_bias_part(b.fc1, F, src, bf, F, 0); }
+        if (sub == "mlp.fc2.weight") { if (!shape_is(shape, ndim, {D, F})) return bad_shape(); return load_linear_part(b.fc2, D, F, src, bf, D, F, 0, D, 0, 0); }
+        if (sub == "mlp.fc2.bias") { if (numel != (size_t)D) return bad_shape(); return load_bias_part(b.fc2, D, src, bf, D, 0); }
+        return fail(VR_ERR_INVALID, "unknown ViT key %s", name_c);
+    }
+    if (name.rfind("resampler.", 0) == 0) {
+        const std::string sub = name.substr(10);
+        if (sub == "query") { if (!shape_is(shape, ndim, {m->Q, E})) return bad_shape(); m->has_query = true; return to_host_f32(src, bf, numel, m->r_query_host); }
+        if (sub == "kv_proj.weight") { if (!shape_is(shape, ndim, {E, D})) return bad_shape(); return load_linear_part(m->r_kvproj, E, D, src, bf, E, D, 0, E, 0, 0); }
+        if (sub == "attn.in_proj_weight") {
+            if (!shape_is(shape, ndim, {3 * E, E})) return bad_shape();
+            std::vector<float> all;
+            VRCHK(to_host_f32(src, bf, (size_t)E * E, all));      // q rows only
+            m->r_wq_host.swap(all);
+            m->has_inproj = true;
+            const char* kv_src = (const char*)src + (size_t)E * E * (bf ? 2 : 4);
+            return load_linear_part(m->r_kv, 2 * E, E, kv_src, bf, 2 * E, E, 0, 2 * E, 0, 0);
+        }
+        if (sub == "attn.in_proj_bias") {
+            if (numel != (size_t)3 * E) return bad_shape();
+            VRCHK(to_host_f32(src, bf, (size_t)E, m->r_bq_host));
+            m->has_inproj_b = true;
+            const char* kv_src = (const char*)src + (size_t)E * (bf ? 2 : 4);
+            return load_bias_part(m->r_kv, 2 * E, kv_src, bf, 2 * E, 0);
+        }
+        if (sub == "attn.out_proj.weight") { if (!shape_is(shape, ndim, {E, E})) return bad_shape(); return load_linear_part(m->r_out, E, E, src, bf, E, E, 0, E, 0, 0); }
+        if (sub == "attn.out_proj.bias") { if (numel != (size_t)E) return bad_shape(); return load_bias_part(m->r_out, E, src, bf, E, 0); }
+        if (sub == "proj") { if (!shape_is(shape, ndim, {E, E})) return bad_shape(); return load_linear_part(m->r_proj, E, E, src, bf, E, E, 1, E, 0, 0); }
+        Vec* v = nullptr;
+        if (sub == "ln_q.weight") v = &m->r_lnq_w; else if (sub == "ln_q.bias") v = &m->r_lnq_b;
+        else if (sub == "ln_kv.weight") v = &m->r_lnkv_w; else if (sub == "ln_kv.bias") v = &m->r_lnkv_b;
+        else if (sub == "ln_post.weight") v = &m->r_lnpost_w; else if (sub == "ln_post.bias") v = &m->r_lnpost_b;
+        if (!v) return fail(VR_ERR_INVALID, "unknown resampler key %s", name_c);
+        if (numel != (size_t)E) return bad_shape();
+        return load_vec(*v, src, bf, E, E);
+    }
+    if (name == "llm.model.embed_tokens.weight") {
+        if (!shape_is(shape, ndim, {c.vocab_size, E})) return bad_shape();
+        VRCHK(m->embed.alloc(numel * 2));
+        HIPCHK(launch_pack_weight(src, bf, c.vocab_size, E, E, 0, m->embed.p, E, c.vocab_size, 0, 0, 0));
+        HIPCHK(hipDeviceSynchronize());
+        m->has_embed = true;
+        return VR_OK;
+    }
+    if (name == "llm.model.norm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(m->final_norm, src, bf, E, E); }
+    if (name.rfind("llm.model.layers.", 0) == 0) {
+        int n = -1, off = 0;
+        if (sscanf(name.c_str(), "llm.model.layers.%d.%n", &n, &off) < 1) return fail(VR_ERR_INVALID, "bad key %s", name_c);
+        if (n >= c.num_layers) return fail(VR_ERR_INVALID, "layer index %d out of range", n);
+        const std::string sub = name.substr(off);
+        DecLayer& l = m->layers[n];
+        if (sub == "input_layernorm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(l.ln1, src, bf, E, E); }
+        if (sub == "post_attention_layernorm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(l.ln2, src, bf, E, E); }
+        for (int part = 0; part < 3; ++part) {
+            static const char* nm[3] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight"};
+            if (sub == nm[part]) {
+                if (!shape_is(shape, ndim, {E, E})) return bad_shape();
+                l.parts_qkv |= 1 << part;
+                return load_linear_part(l.qkv, 3 * E, E, src, bf, E, E, 0, E, 0, part * E);
+            }
+        }
+        if (sub == "self_attn.o_proj.weight") { if (!shape_is(shape, ndim, {E, E})) return bad_shape(); return load_linear_part(l.o, E, E, src, bf, E, E, 0, E, 0, 0); }
+        if (sub == "mlp.gate_proj.weight" || sub == "mlp.up_proj.weight") {
+            if (!shape_is(shape, ndim, {I, E})) return bad_shape();
+            const int up = sub == "mlp.up_proj.weight";
+            l.parts_gu |= 1 << up;
+            // 16-row interleave: [16 gate | 16 up | ...] (EPI_SWIGLU)
+            return load_linear_part(l.gu, 2 * I, E, src, bf, I, E, 0, 16, 32, up * 16);
+        }
+        if (sub == "mlp.down_proj.weight") { if (!shape_is(shape, ndim, {E, I})) return bad_shape(); return load_linear_part(l.down, E, I, src, bf, E, I, 0, E, 0, 0); }
+        return fail(VR_ERR_INVALID, "unknown decoder key %s", name_c);
+    }
+    return fail(VR_ERR_INVALID, "unknown weight key %s", name_c);
+}
+
+// ---------------------------------------------------------------------- derived tables ---
+// fp32 sincos table of resampler.py:38-90 (numpy float32 arithmetic restated)
+static void sincos_2d_host(int E, int gh, int gw, std::vector<float>& out) {
+    const int half = E / 2, quarter = half / 2;
+    out.assign((size_t)gh * gw * E, 0.f);
+    std::vector<float> omega(quarter);
+    for (int i = 0; i < quarter; ++i) {
+        float o = (float)i / ((float)half / 2.0f);
+        omega[i] = 1.0f / powf(10000.0f, o);
+    }
+    for (int y = 0; y < gh; ++y)
+        for (int x = 0; x < gw; ++x) {
+            float* row = out.data() + ((size_t)y * gw + x) * E;
+            // first half <- grid[0] = column index (meshgrid(w, h), "w goes first"); second <- row index
+            for (int i = 0; i < quarter; ++i) {
+                const float a = (float)x * omega[i], b = (float)y * omega[i];
+                row[i] = sinf(a); row[quarter + i] = cosf(a);
+                row[half + i] = sinf(b); row[half + quarter + i] = cosf(b);
+            }
+        }
+}
+
+// bicubic (a = -0.5) anti-aliased separable resample, align_corners=False: the algorithm of
+// F.interpolate(mode="bicubic", antialias=True) used by timm's resample_abs_pos_embed
+// (timm/layers/pos_embed.py:46).  in [gi][gi][D] -> out [gh][gw][D].
+static inline float cubic_aa(float x) {
+    const float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((x - 5.0f) * x + 8.0f) * x - 4.0f) * a;
+    return 0.0f;
+}
+static void aa_weights(int in, int out, std::vector<int>& xmin, std::vector<int>& xsize, std::vector<float>& w, int& maxk) {
+    const float scale = (float)in / (float)out;
+    const float support = (scale >= 1.0f) ? 2.0f * scale : 2.0f;
+    const float invscale = (scale >= 1.0f) ? 1.0f / scale : 1.0f;
+    maxk = (int)ceilf(support) * 2 + 1;
+    xmin.resize(out); xsize.resize(out); w.assign((size_t)out * maxk, 0.f);
+    for (int i = 0; i < out; ++i) {
+        const float center = scale * ((float)i + 0.5f);
+        int lo = std::max(0, (int)(center - support + 0.5f));
+        int hi = std::min(in, (int)(center + support + 0.5f));
+        xmin[i] = lo; xsize[i] = hi - lo;
+        float tot = 0.f;
+        for (int j = 0; j < xsize[i]; ++j) {
+            const float ww = cubic_aa(((float)(j + lo) - center + 0.5f) * invscale);
+            w[(size_t)i * maxk + j] = ww; tot += ww;
+        }
+        for (int j = 0; j < xsize[i]; ++j) w[(size_t)i * maxk + j] /= tot;
+    }
+}
+static void resample_pos_host(const std::vector<float>& pe, int gi, int D, int gh, int gw, std::vector<float>& out) {
+    out.assign((size_t)gh * gw * D, 0.f);
+    if (gh == gi && gw == gi) { out = pe; return; }
+    std::vector<int> xm, xs, ym, ys; std::vector<float> xw, yw; int xk, yk;
+    aa_weights(gi, gw, xm, xs, xw, xk);
+    aa_weights(gi, gh, ym, ys, yw, yk);
+    std::vector<float> tmp((size_t)gi * gw * D, 0.f);      // horizontal pass
+    for (int y = 0; y < gi; ++y)
+        for (int x = 0; x < gw; ++x) {
+            float* o = tmp.data() + ((size_t)y * gw + x) * D;
+            for (int j = 0; j < xs[x]; ++j) {
+                const float ww = xw[(size_t)x * xk + j];
+                const float* s = pe.data() + ((size_t)y * gi + xm[x] + j) * D;
+                for (int d = 0; d < D; ++d) o[d] += ww * s[d];
+            }
+        }
+    for (int y = 0; y < gh; ++y)                             // vertical pass
+        for (int x = 0; x < gw; ++x) {
+            float* o = out.data() + ((size_t)y * gw + x) * D;
+            for (int j = 0; j < ys[y]; ++j) {
+                const float ww = yw[(size_t)y * yk + j];
+                const float* s = tmp.data() + ((size_t)(ym[y] + j) * gw + x) * D;
+                for (int d = 0; d < D; ++d) o[d] += ww * s[d];
+            }
+        }
+}
+
+static GemmArgs gemm_args(const void* A, int lda, const Linear& L, int M, void* out, int ldo) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = L.w.p; a.ldw = L.k_pad; a.M = M; a.N = L.n_pad; a.K = L.k_pad;
+    a.bias = L.has_b ? L.b.as<float>() : nullptr;
+    a.out = out; a.ldo = ldo; a.alpha = 1.0f;
+    return a;
+}
+
+static int alloc_workspace(vr_model_s* m) {
+    const vr_config_t& c = m->c;
+    const int64_t M = pad128l((int64_t)c.max_images * c.max_patches);
+    const int64_t T = pad128l(c.max_tokens);
+    const int64_t R = pad128l((int64_t)c.max_images * m->Q);
+    m->Mcap = M; m->Tcap = T; m->Rcap = R;
+    const int E = m->E, Dp = m->Dp;
+    VRCHK(m->w_im2col.alloc((size_t)M * m->Kpe_p * 2));
+    VRCHK(m->w_hvit.alloc((size_t)M * Dp * 4));
+    VRCHK(m->w_xn.alloc((size_t)M * Dp * 2));
+    VRCHK(m->w_qkv.alloc((size_t)M * pad128(3 * m->D) * 2));
+    VRCHK(m->w_att.alloc((size_t)M * Dp * 2));
+    VRCHK(m->w_mlp.alloc((size_t)M * m->Fp * 2));
+    VRCHK(m->w_kv32.alloc((size_t)M * E * 4));
+    VRCHK(m->w_xkv.alloc((size_t)M * E * 2));
+    VRCHK(m->w_KV.alloc((size_t)M * 2 * E * 2));
+    VRCHK(m->w_ratt.alloc((size_t)R * E * 2));
+    VRCHK(m->w_rout.alloc((size_t)R * E * 4));
+    VRCHK(m->w_rln.alloc((size_t)R * E * 2));
+    VRCHK(m->w_h.alloc((size_t)T * E * 4));
+    VRCHK(m->w_dxn.alloc((size_t)T * E * 2));
+    VRCHK(m->w_dqkv.alloc((size_t)T * 3 * E * 2));
+    VRCHK(m->w_datt.alloc((size_t)T * E * 2));
+    VRCHK(m->w_dact.alloc((size_t)T * m->Ip * 2));
+    VRCHK(m->w_cu.alloc((size_t)(c.max_images + c.max_seqs + 8) * 2 * 4));
+    VRCHK(m->w_ids.alloc((size_t)T * 4));
+    VRCHK(m->w_seq.alloc((size_t)(c.max_seqs + 1) * 4));
+    VRCHK(m->w_pos.alloc((size_t)T * 4));
+    VRCHK(m->w_rowmap.alloc((size_t)R * 4));
+    VRCHK(m->w_imgptr.alloc((size_t)c.max_images * 8));
+    VRCHK(m->w_out.alloc((size_t)c.max_seqs * E * 4));
+    return VR_OK;
+}
+
+extern "C" int vr_model_finalize(vr_model_t m) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    VRCHK(set_dev(m->device));
+    const vr_config_t& c = m->c;
+    const int E = m->E;
+    // ---- completeness
+    auto need = [&](bool ok, const char* what) { return ok ? VR_OK : fail(VR_ERR_STATE, "missing weight: %s", what); };
+    VRCHK(need(m->patch.has_w && m->patch.has_b, "vpm.patch_embed.proj"));
+    VRCHK(need(m->has_pos, "vpm.pos_embed"));
+    VRCHK(need(m->vit_nw.ok && m->vit_nb.ok, "vpm.norm"));
+    for (int n = 0; n < c.vit_depth; ++n) {
+        const VitBlock& b = m->blocks[n];
+        const bool ok = b.n1w.ok && b.n1b.ok && b.n2w.ok && b.n2b.ok && b.qkv.has_w && b.qkv.has_b && b.proj.has_w &&
+                        b.proj.has_b && b.fc1.has_w && b.fc1.has_b && b.fc2.has_w && b.fc2.has_b;
+        if (!ok) return fail(VR_ERR_STATE, "missing weight in vpm.blocks.%d", n);
+    }
+    VRCHK(need(m->has_query && m->has_inproj && m->has_inproj_b, "resampler.query / attn.in_proj"));
+    VRCHK(need(m->r_kvproj.has_w && m->r_kv.has_w && m->r_kv.has_b && m->r_out.has_w && m->r_out.has_b && m->r_proj.has_w,
+               "resampler linear weights"));
+    VRCHK(need(m->r_lnq_w.ok && m->r_lnq_b.ok && m->r_lnkv_w.ok && m->r_lnkv_b.ok && m->r_lnpost_w.ok && m->r_lnpost_b.ok,
+               "resampler layer norms"));
+    VRCHK(need(m->has_embed && m->final_norm.ok, "llm.model.embed_tokens / norm"));
+    for (int n = 0; n < c.num_layers; ++n) {
+        const DecLayer& l = m->layers[n];
+        const bool ok = l.ln1.ok && l.ln2.ok && l.parts_qkv == 7 && l.parts_gu == 3 && l.o.has_w && l.down.has_w;
+        if (!ok) return fail(VR_ERR_STATE, "missing weight in llm.model.layers.%d", n);
+    }
+    // ---- resampler query projection (batch-invariant, computed once in fp32 on the host):
+    //      q = (ln_q(query) + sincos(8x8)) @ Wq^T + bq          resampler.py:157-160
+    {
+        const int Q = m->Q;
+        std::vector<float> lw(E), lb(E), pq;
+        HIPCHK(hipMemcpy(lw.data(), m->r_lnq_w.v.p, (size_t)E * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lb.data(), m->r_lnq_b.v.p, (size_t)E * 4, hipMemcpyDeviceToHost));
+        const int g = (int)lround(sqrt((double)Q));
+        sincos_2d_host(E, g, g, pq);
+        std::vector<float> x((size_t)Q * E), out((size_t)Q * E);
+        for (int q = 0; q < Q; ++q) {
+            const float* s = m->r_query_host.data() + (size_t)q * E;
+            double mu = 0; for (int i = 0; i < E; ++i) mu += s[i]; mu /= E;
+            double var = 0; for (int i = 0; i < E; ++i) { const double d = s[i] - mu; var += d * d; } var /= E;
+            const float rstd = (float)(1.0 / sqrt(var + (double)c.resampler_ln_eps));
+            for (int i = 0; i < E; ++i) x[(size_t)q * E + i] = ((float)(s[i] - mu)) * rstd * lw[i] + lb[i] + pq[(size_t)q * E + i];
+        }
+        for (int q = 0; q < Q; ++q)
+            for (int n = 0; n < E; ++n) {
+                const float* wr = m->r_wq_host.data() + (size_t)n * E;
+                const float* xr = x.data() + (size_t)q * E;
+                float acc = 0.f;
+                for (int i = 0; i < E; ++i) acc += xr[i] * wr[i];
+                out[(size_t)q * E + n] = acc + m->r_bq_host[n];
+            }
+        DevBuf t;
+        VRCHK(t.alloc(out.size() * 4));
+        HIPCHK(hipMemcpy(t.p, out.data(), out.size() * 4, hipMemcpyHostToDevice));
+        VRCHK(m->r_q.alloc((size_t)pad128(Q) * E * 2));
+        HIPCHK(launch_f32_to_bf16(t.as<float>(), m->r_q.p, out.size(), 0));
+        HIPCHK(hipDeviceSynchronize());
+        t.free();
+    }
+    // ---- RoPE table [pos][cos 32 | sin 32], fp32 (modeling_minicpm.py:142-172)
+    {
+        m->rope_len = std::max(c.max_tokens, 16);
+        std::vector<float> tab((size_t)m->rope_len * 64);
+        float inv[32];
+        for (int i = 0; i < 32; ++i) inv[i] = 1.0f / powf(c.rope_theta, (float)(2 * i) / 64.0f);
+        for (int p = 0; p < m->rope_len; ++p)
+            for (int i = 0; i < 32; ++i) {
+                const float a = (float)p * inv[i];
+                tab[(size_t)p * 64 + i] = cosf(a);
+                tab[(size_t)p * 64 + 32 + i] = sinf(a);
+            }
+        VRCHK(m->rope.alloc(tab.size() * 4));
+        HIPCHK(hipMemcpy(m->rope.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!m->w_h.p) VRCHK(alloc_workspace(m));
+    m->finalized = true;
+    return VR_OK;
+}
+
+// per-grid constants: resampled ViT pos-embed and the k-side position term of the resampler
+static int get_grid(vr_model_s* m, int gh, int gw, GridTables** out) {
+    auto key = std::make_pair(gh, gw);
+    auto it = m->grids.find(key);
+    if (it != m->grids.end()) { *out = &it->second; return VR_OK; }
+    const int N = gh * gw, D = m->D, Dp = m->Dp, E = m->E;
+    GridTables g;
+    g.gh = gh; g.gw = gw;
+    {   // K3: timm resample_abs_pos_embed, once per grid instead of once per forward
+        std::vector<float> rs, padded((size_t)N * Dp, 0.f);
+        resample_pos_host(m->pos_embed_host, m->c.vit_pos_grid, D, gh, gw, rs);
+        for (int r = 0; r < N; ++r) memcpy(padded.data() + (size_t)r * Dp, rs.data() + (size_t)r * D, (size_t)D * 4);
+        VRCHK(g.vit_pos.alloc(padded.size() * 4));
+        HIPCHK(hipMemcpy(g.vit_pos.p, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+    }
+    {   // K10/K11: k = (x + pos) Wk^T + bk = x Wk^T + bk + (pos Wk^T); the last term is a
+        // per-position bias computed once per grid with two bf16 passes (hi + lo split of the
+        // fp32 sincos table keeps ~16 mantissa bits).
+        std::vector<float> sc;
+        sincos_2d_host(E, gh, gw, sc);
+        const int Np = pad128(N);
+        DevBuf f32, hi, lo, tmp;
+        VRCHK(f32.alloc((size_t)Np * E * 4));
+        VRCHK(hi.alloc((size_t)Np * E * 2));
+        VRCHK(lo.alloc((size_t)Np * E * 2));
+        VRCHK(tmp.alloc((size_t)Np * E * 4));
+        VRCHK(g.pos_k.alloc((size_t)Np * E * 4));
+        HIPCHK(hipMemcpy(f32.p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(launch_split_bf16(f32.as<float>(), hi.p, lo.p, (size_t)N * E, 0));
+        GemmArgs a{};
+        a.A = hi.p; a.lda = E; a.W = m->r_kv.w.p; a.ldw = m->r_kv.k_pad; a.M = N; a.N = E; a.K = E;
+        a.out = tmp.p; a.ldo = E; a.alpha = 1.f;
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, 0));
+        a.A = lo.p; a.resid = tmp.as<float>(); a.out = g.pos_k.p;
+        HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, 0));
+        HIPCHK(hipDeviceSynchronize());
+        f32.free(); hi.free(); lo.free(); tmp.free();
+    }
+    auto ins = m->grids.emplace(key, std::move(g));
+    *out = &ins.first->second;
+    return VR_OK;
+}
+
+// ---------------------------------------------------------------------------------- taps ---
+static int tap_store(vr_model_s* m, const char* name, const void* dev, int64_t rows, int64_t cols, int64_t ld,
+                     bool is_bf16, hipStream_t s) {
+    if (!m->taps_on) return VR_OK;
+    HIPCHK(hipStreamSynchronize(s));
+    Tap& t = m->taps[name];
+    t.rows = rows; t.cols = cols;
+    t.data.resize((size_t)rows * cols);
+    const size_t esz = is_bf16 ? 2 : 4;
+    std::vector<char> raw((size_t)rows * ld * esz);
+    HIPCHK(hipMemcpy(raw.data(), dev, raw.size(), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t cc = 0; cc < cols; ++cc) {
+            if (is_bf16) {
+                uint16_t b; memcpy(&b, raw.data() + ((size_t)r * ld + cc) * 2, 2);
+                uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4);
+                t.data[(size_t)r * cols + cc] = f;
+            } else {
+                float f; memcpy(&f, raw.data() + ((size_t)r * ld + cc) * 4, 4);
+                t.data[(size_t)r * cols + cc] = f;
+            }
+        }
+    return VR_OK;
+}
+
+extern "C" int vr_model_set_taps(vr_model_t m, int32_t enable) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    m->taps_on = enable != 0;
+    if (!enable) m->taps.clear();
+    return VR_OK;
+}
+
+extern "C" int vr_model_tap(vr_model_t m, const char* name, float* out, int64_t rows, int64_t cols) {
+    if (!m || !name || !out) return fail(VR_ERR_INVALID, "NULL argument");
+    auto it = m->taps.find(name);
+    if (it == m->taps.end()) return fail(VR_ERR_STATE, "tap %s not recorded (enable taps, then encode)", name);
+    const Tap& t = it->second;
+    if (rows > t.rows || cols != t.cols) return fail(VR_ERR_INVALID, "tap %s is [%lld][%lld]", name, (long long)t.rows, (long long)t.cols);
+    memcpy(out, t.data.data(), (size_t)rows * cols * 4);
+    return VR_OK;
+}
+
+// -------------------------------------------------------------------------------- encode ---
+// ViT + resampler for `n` same-shape slices; writes resampler rows into the decoder stream.
+static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostarray, int n, int H, int W,
+                            const int32_t* rowmap_host /* [n*Q] */, bool first_group, hipStream_t s) {
+    const vr_config_t& c = m->c;
+    const int P = c.patch_size, gh = H / P, gw = W / P, N = gh * gw;
+    const int D = m->D, Dp = m->Dp, E = m->E, Q = m->Q;
+    const int M = n * N;
+    GridTables* g = nullptr;
+    VRCHK(get_grid(m, gh, gw, &g));
+
+    // dev_imgs_hostarray / rowmap_host live in the pinned arena (see vr_encode)
+    HIPCHK(hipMemcpyAsync(m->w_imgptr.p, dev_imgs_hostarray, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    int* cu = (int*)arena_take(m, (size_t)2 * (n + 1) * 4);
+    for (int i = 0; i <= n; ++i) { cu[i] = i * N; cu[n + 1 + i] = i * Q; }
+    HIPCHK(hipMemcpyAsync(m->w_cu.p, cu, (size_t)2 * (n + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->w_rowmap.p, rowmap_host, (size_t)n * Q * 4, hipMemcpyHostToDevice, s));
+    const int* cu_tok = m->w_cu.as<int>();
+    const int* cu_qry = m->w_cu.as<int>() + (n + 1);
+
+    float* h = m->w_hvit.as<float>();
+    // K1+K2+K3: normalise + im2col, patch GEMM + bias + resampled pos-embed -> fp32 residual stream
+    HIPCHK(launch_im2col((const uint8_t* const*)m->w_imgptr.p, n, H, W, P, m->w_im2col.p, m->Kpe_p, s));
+    {
+        GemmArgs a = gemm_args(m->w_im2col.p, m->Kpe_p, m->patch, M, h, Dp);
+        a.rowbias = g->vit_pos.as<float>(); a.rowbias_period = N; a.rowbias_ld = Dp; a.rowbias_cols = Dp;
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s));
+    }
+    if (first_group) VRCHK(tap_store(m, "vit_embed", h, N, D, Dp, false, s));
+    const int ldqkv = pad128(3 * D);
+    for (int l = 0; l < c.vit_depth; ++l) {
+        const VitBlock& b = m->blocks[l];
+        HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
+        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_GLDS, s)); }
+        {
+            AttnArgs a{};
+            a.q = m->w_qkv.p; a.ldq = ldqkv;
+            a.k = (const char*)m->w_qkv.p + (size_t)D * 2; a.ldk = ldqkv;
+            a.v = (const char*)m->w_qkv.p + (size_t)2 * D * 2; a.ldv = ldqkv;
+            a.out = m->w_att.p; a.ldo = Dp; a.cu_q = cu_tok; a.cu_kv = cu_tok; a.B = n; a.heads = c.vit_heads;
+            a.head_dim = 72; a.max_q = N; a.causal = 0; a.q_shared = 0; a.scale = 1.0f / sqrtf(72.0f);
+            HIPCHK(launch_attention(a, s));
+        }
+        { GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
+        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        if (l == 0 && first_group) VRCHK(tap_store(m, "vit_block0", h, N, D, Dp, false, s));
+    }
+    HIPCHK(launch_layernorm(h, M, D, Dp, m->vit_nw.v.as<float>(), m->vit_nb.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
+    if (first_group) VRCHK(tap_store(m, "vit_out", m->w_xn.p, N, D, Dp, true, s));
+
+    // ---- resampler (resampler.py:146-168)
+    { GemmArgs a = gemm_args(m->w_xn.p, Dp, m->r_kvproj, M, m->w_kv32.p, E); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s)); }
+    HIPCHK(launch_layernorm(m->w_kv32.as<float>(), M, E, E, m->r_lnkv_w.v.as<float>(), m->r_lnkv_b.v.as<float>(),
+                            c.resampler_ln_eps, m->w_xkv.p, E, s));
+    {   // fused k|v in-projection; the k half gets the per-position term pos_k[row % N]
+        GemmArgs a = gemm_args(m->w_xkv.p, E, m->r_kv, M, m->w_KV.p, 2 * E);
+        a.rowbias = g->pos_k.as<float>(); a.rowbias_period = N; a.rowbias_ld = E; a.rowbias_cols = E;
+        HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_GLDS, s));
+    }
+    {
+        AttnArgs a{};
+        a.q = m->r_q.p; a.ldq = E; a.k = m->w_KV.p; a.ldk = 2 * E; a.v = (const char*)m->w_KV.p + (size_t)E * 2; a.ldv = 2 * E;
+        a.out = m->w_ratt.p; a.ldo = E; a.cu_q = cu_qry; a.cu_kv = cu_tok; a.B = n; a.heads = E / 128; a.head_dim = 128;
+        a.max_q = Q; a.causal = 0; a.q_shared = 1; a.scale = 1.0f / sqrtf(128.0f);
+        HIPCHK(launch_attention(a, s));
+    }
+    const int R = n * Q;
+    { GemmArgs a = gemm_args(m->w_ratt.p, E, m->r_out, R, m->w_rout.p, E); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s)); }
+    HIPCHK(launch_layernorm(m->w_rout.as<float>(), R, E, E, m->r_lnpost_w.v.as<float>(), m->r_lnpost_b.v.as<float>(),
+                            c.resampler_ln_eps, m->w_rln.p, E, s));
+    if (first_group && m->taps_on) {   // un-scattered copy for the tap
+        GemmArgs a = gemm_args(m->w_rln.p, E, m->r_proj, Q, m->w_rout.p, E);
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s));
+        VRCHK(tap_store(m, "resampler_out", m->w_rout.p, Q, E, E, false, s));
+    }
+    {   // x @ proj, scattered straight into the decoder's fp32 input rows (image_bound scatter_,
+        // modeling_minicpmv.py:148-166; vision rows are NOT scaled by scale_emb)
+        GemmArgs a = gemm_args(m->w_rln.p, E, m->r_proj, R, m->w_h.p, E);
+        a.rowmap = m->w_rowmap.as<int>();
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s));
+    }
+    return VR_OK;
+}
+
+extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
+                         int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
+                         const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    if (!m->finalized) return fail(VR_ERR_STATE, "vr_model_finalize() has not succeeded");
+    if (B <= 0 || !input_ids || !seq_offsets || !out_reps) return fail(VR_ERR_INVALID, "empty batch or NULL argument");
+    if (n_slices > 0 && (!slices || !slice_hw || !vision_rows)) return fail(VR_ERR_INVALID, "NULL slice arguments");
+    VRCHK(set_dev(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const vr_config_t& c = m->c;
+    const int E = m->E, Q = m->Q;
+    const int T = seq_offsets[B];
+    if (seq_offsets[0] != 0) return fail(VR_ERR_INVALID, "seq_offsets[0] must be 0");
+    if (B > c.max_seqs) return fail(VR_ERR_CAPACITY, "B=%d exceeds max_seqs=%d", B, c.max_seqs);
+    if (T > c.max_tokens) return fail(VR_ERR_CAPACITY, "T=%d tokens exceed max_tokens=%d", T, c.max_tokens);
+    for (int i = 0; i < B; ++i)
+        if (seq_offsets[i + 1] <= seq_offsets[i]) return fail(VR_ERR_INVALID, "empty sequence %d", i);
+    for (int t = 0; t < T; ++t)
+        if (input_ids[t] < 0 || input_ids[t] >= c.vocab_size) return fail(VR_ERR_INVALID, "token id %d out of range at %d", input_ids[t], t);
+    for (int i = 0; i < n_slices * Q; ++i)
+        if (vision_rows[i] >= T) return fail(VR_ERR_INVALID, "vision row %d out of range", vision_rows[i]);
+
+    // ---- K13: token embeddings * scale_emb into the fp32 stream
+    VRCHK(arena_begin(m, (size_t)T * 4 + (size_t)(B + 1) * 4 + (size_t)n_slices * (Q * 4 + 8 + 64 * 3) + 4096));
+    {
+        int* a_ids = (int*)arena_take(m, (size_t)T * 4);
+        int* a_seq = (int*)arena_take(m, (size_t)(B + 1) * 4);
+        memcpy(a_ids, input_ids, (size_t)T * 4);
+        memcpy(a_seq, seq_offsets, (size_t)(B + 1) * 4);
+        HIPCHK(hipMemcpyAsync(m->w_ids.p, a_ids, (size_t)T * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->w_seq.p, a_seq, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, c.scale_emb, m->w_h.as<float>(), s));
+    HIPCHK(launch_iota_pos(m->w_seq.as<int>(), B, m->w_pos.as<int>(), s));
+
+    // ---- vision: group slices by shape, chunk to the workspace
+    if (n_slices > 0) {
+        size_t pix_total = 0;
+        std::vector<size_t> pix_off(n_slices);
+        for (int i = 0; i < n_slices; ++i) {
+            const int H = slice_hw[2 * i], W = slice_hw[2 * i + 1];
+            if (H <= 0 || W <= 0 || H % c.patch_size || W % c.patch_size)
+                return fail(VR_ERR_INVALID, "slice %d: %dx%d is not a multiple of the patch size", i, H, W);
+            if ((H / c.patch_size) * (W / c.patch_size) > c.max_patches)
+                return fail(VR_ERR_CAPACITY, "slice %d has more than max_patches=%d patches", i, c.max_patches);
+            pix_off[i] = pix_total;
+            pix_total += ((size_t)H * W * 3 + 15) / 16 * 16;
+        }
+        std::vector<const uint8_t*> dev_ptr(n_slices);
+        if (slices_on_device) {
+            for (int i = 0; i < n_slices; ++i) dev_ptr[i] = slices[i];
+        } else {
+            if (m->w_pix.bytes < pix_total) VRCHK(m->w_pix.alloc(pix_total));
+            for (int i = 0; i < n_slices; ++i) {
+                const size_t nb = (size_t)slice_hw[2 * i] * slice_hw[2 * i + 1] * 3;
+                HIPCHK(hipMemcpyAsync((char*)m->w_pix.p + pix_off[i], slices[i], nb, hipMemcpyHostToDevice, s));
+                dev_ptr[i] = (const uint8_t*)m->w_pix.p + pix_off[i];
+            }
+        }
+        std::vector<char> done(n_slices, 0);
+        bool first = true;
+        for (int i = 0; i < n_slices; ++i) {
+            if (done[i]) continue;
+            const int H = slice_hw[2 * i], W = slice_hw[2 * i + 1];
+            const int N = (H / c.patch_size) * (W / c.patch_size);
+            std::vector<int> idx;
+            for (int j = i; j < n_slices; ++j)
+                if (!done[j] && slice_hw[2 * j] == H && slice_hw[2 * j + 1] == W) { idx.push_back(j); done[j] = 1; }
+            const int per_pass = std::max(1, (int)std::min<int64_t>(c.max_images, ((int64_t)c.max_images * c.max_patches) / N));
+            for (size_t lo = 0; lo < idx.size(); lo += per_pass) {
+                const int n = (int)std::min<size_t>(per_pass, idx.size() - lo);
+                const uint8_t** ptrs = (const uint8_t**)arena_take(m, (size_t)n * 8);
+                int32_t* rowmap = (int32_t*)arena_take(m, (size_t)n * Q * 4);
+                for (int k = 0; k < n; ++k) {
+                    ptrs[k] = dev_ptr[idx[lo + k]];
+                    memcpy(rowmap + (size_t)k * Q, vision_rows + (size_t)idx[lo + k] * Q, (size_t)Q * 4);
+                }
+                VRCHK(run_vision_group(m, ptrs, n, H, W, rowmap, first, s));
+                first = false;
+            }
+        }
+    }
+    VRCHK(tap_store(m, "inputs_embeds", m->w_h.p, T, E, E, false, s));
+
+    // ---- decoder (modeling_minicpm.py:939-1004, 1147-1304), packed ragged sequences
+    float* h = m->w_h.as<float>();
+    const int* seq = m->w_seq.as<int>();
+    int max_len = 0;
+    for (int i = 0; i < B; ++i) max_len = std::max(max_len, seq_offsets[i + 1] - seq_offsets[i]);
+    if (max_len > m->rope_len) return fail(VR_ERR_CAPACITY, "sequence of %d tokens exceeds the RoPE table", max_len);
+    for (int l = 0; l < c.num_layers; ++l) {
+        const DecLayer& L = m->layers[l];
+        HIPCHK(launch_rmsnorm(h, T, E, E, L.ln1.v.as<float>(), c.rms_norm_eps, m->w_dxn.p, E, s));
+        {
+            GemmArgs a = gemm_args(m->w_dxn.p, E, L.qkv, T, m->w_dqkv.p, 3 * E);
+            a.rope_pos = m->w_pos.as<int>(); a.rope_table = m->rope.as<float>(); a.rope_cols = 2 * E;
+            HIPCHK(launch_gemm(a, EPI_ROPE, GEMM_VARIANT_GLDS, s));
+        }
+        {
+            AttnArgs a{};
+            a.q = m->w_dqkv.p; a.ldq = 3 * E; a.k = (const char*)m->w_dqkv.p + (size_t)E * 2; a.ldk = 3 * E;
+            a.v = (const char*)m->w_dqkv.p + (size_t)2 * E * 2; a.ldv = 3 * E;
+            a.out = m->w_datt.p; a.ldo = E; a.cu_q = seq; a.cu_kv = seq; a.B = B; a.heads = c.num_heads; a.head_dim = 64;
+            a.max_q = max_len; a.causal = 1; a.q_shared = 0; a.scale = 1.0f / sqrtf(64.0f);
+            HIPCHK(launch_attention(a, s));
+        }
+        { GemmArgs a = gemm_args(m->w_datt.p, E, L.o, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        HIPCHK(launch_rmsnorm(h, T, E, E, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_dxn.p, E, s));
+        { GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_dact.p, m->Ip, L.down, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        if (l == 0) VRCHK(tap_store(m, "dec_layer0", h, T, E, E, false, s));
+    }
+    // ---- K19+K20: final norm + wmean pool + L2 normalise
+    float* tap_hidden = nullptr;   // scratch f32 [T][E] for the post-norm hidden states
+    if (m->taps_on && (size_t)T * E * 4 <= m->w_kv32.bytes) tap_hidden = m->w_kv32.as<float>();
+    float* dst = out_on_device ? out_reps : m->w_out.as<float>();
+    HIPCHK(launch_pool(h, seq, B, E, m->final_norm.v.as<float>(), c.rms_norm_eps, dst, tap_hidden, s));
+    if (tap_hidden) VRCHK(tap_store(m, "last_hidden", tap_hidden, T, E, E, false, s));
+    HIPCHK(hipEventRecord(m->arena_ev, s));
+    m->arena_pending = true;
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out_reps, dst, (size_t)B * E * 4, hipMemcpyDeviceToHost, s));
+    if (!out_on_device || (n_slices > 0 && !slices_on_device)) HIPCHK(hipStreamSynchronize(s));   // host buffers consumed
+    return VR_OK;
+}
+
+// --------------------------------------------------------------------------------- index ---
+struct vr_index_s {
+    int device = 0, dim = 0;
+    int64_t cap = 0, n = 0;
+    DevBuf f32, bf16;                 // [cap_pad][dim]
+    DevBuf q32, qbf, cs, ci, os, oi;  // query staging / candidates / outputs
+    int64_t qcap = 0, ccap = 0;
+};
+
+extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_index_t* out) {
+    if (!out || dim <= 0 || capacity <= 0) return fail(VR_ERR_INVALID, "bad index arguments");
+    if (dim % 64 || dim > 2560) return fail(VR_ERR_INVALID, "dim %d must be a multiple of 64 and <= 2560", dim);
+    if (capacity >= ((int64_t)1 << 31) - 256) return fail(VR_ERR_INVALID, "capacity too large for 32-bit row ids");
+    VRCHK(set_dev(device_id));
+    vr_index_s* ix = new vr_index_s();
+    ix->device = device_id; ix->dim = dim; ix->cap = capacity;
+    const int64_t cp = pad128l(capacity);
+    int r = ix->f32.alloc((size_t)cp * dim * 4);
+    if (r == VR_OK) r = ix->bf16.alloc((size_t)cp * dim * 2);
+    if (r != VR_OK) { ix->f32.free(); ix->bf16.free(); delete ix; return r; }
+    *out = ix;
+    return VR_OK;
+}
+
+extern "C" int vr_index_destroy(vr_index_t ix) {
+    if (!ix) return VR_OK;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->os, &ix->oi}) b->free();
+    delete ix;
+    return VR_OK;
+}
+
+extern "C" int vr_index_reset(vr_index_t ix) {
+    if (!ix) return fail(VR_ERR_INVALID, "NULL index");
+    ix->n = 0;
+    return VR_OK;
+}
+
+extern "C" int vr_index_size(vr_index_t ix, int64_t* n) {
+    if (!ix || !n) return fail(VR_ERR_INVALID, "NULL argument");
+    *n = ix->n;
+    return VR_OK;
+}
+
+extern "C" int vr_index_add(vr_index_t ix, const float* reps, int64_t n, int32_t on_device, void* stream) {
+    if (!ix || (!reps && n > 0) || n < 0) return fail(VR_ERR_INVALID, "bad arguments");
+    if (n == 0) return VR_OK;
+    if (ix->n + n > ix->cap) return fail(VR_ERR_CAPACITY, "index capacity %lld exceeded", (long long)ix->cap);
+    VRCHK(set_dev(ix->device));
+    hipStream_t s = (hipStream_t)stream;
+    float* dst = ix->f32.as<float>() + (size_t)ix->n * ix->dim;
+    HIPCHK(hipMemcpyAsync(dst, reps, (size_t)n * ix->dim * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    HIPCHK(launch_f32_to_bf16(dst, (char*)ix->bf16.p + (size_t)ix->n * ix->dim * 2, (size_t)n * ix->dim, s));
+    if (!on_device) HIPCHK(hipStreamSynchronize(s));
+    ix->n += n;
+    return VR_OK;
+}
+
+extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k, float* out_scores,
+                               int64_t* out_ids, int32_t on_device, void* stream) {
+    if (!ix || !queries || !out_scores || !out_ids || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
+    const int kp = search_kprime(k);
+    if (kp == 0) return fail(VR_ERR_INVALID, "k=%d unsupported (1..26)", k);
+    VRCHK(set_dev(ix->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int dim = ix->dim;
+    const int64_t nqp = pad128l(nq);
+    if (ix->qcap < nqp) {
+        VRCHK(ix->q32.alloc((size_t)nqp * dim * 4));
+        VRCHK(ix->qbf.alloc((size_t)nqp * dim * 2));
+        ix->qcap = nqp;
+    }
+    const float* q32 = queries;
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(ix->q32.p, queries, (size_t)nq * dim * 4, hipMemcpyHostToDevice, s));
+        q32 = ix->q32.as<float>();
+    }
+    HIPCHK(hipMemsetAsync(ix->qbf.p, 0, (size_t)nqp * dim * 2, s));
+    HIPCHK(launch_f32_to_bf16(q32, ix->qbf.p, (size_t)nq * dim, s));
+    float* os = out_scores; int64_t* oi = out_ids;
+    if (!on_device) {
+        VRCHK(ix->os.alloc((size_t)nq * k * 4));
+        VRCHK(ix->oi.alloc((size_t)nq * k * 8));
+        os = ix->os.as<float>(); oi = ix->oi.as<int64_t>();
+    }
+    if (ix->n == 0) {
+        std::vector<float> sc((size_t)nq * k, -INFINITY);
+        std::vector<int64_t> id((size_t)nq * k, -1);
+        HIPCHK(hipMemcpyAsync(os, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(oi, id.data(), id.size() * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        SearchArgs a{};
+        a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
+        a.q_bf16 = ix->qbf.p; a.q_f32 = q32; a.nq = nq; a.k = k;
+        a.n_chunks = search_num_chunks(ix->n, nq);
+        const int64_t need = nqp * a.n_chunks * kp;
+        if (ix->ccap < need) {
+            VRCHK(ix->cs.alloc((size_t)need * 4));
+            VRCHK(ix->ci.alloc((size_t)need * 4));
+            ix->ccap = need;
+        }
+        a.cand_scores = ix->cs.as<float>(); a.cand_ids = ix->ci.as<int>();
+        a.out_scores = os; a.out_ids = oi;
+        HIPCHK(launch_search(a, s));
+    }
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(out_scores, os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out_ids, oi, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return VR_OK;
+}
+
+extern "C" int vr_topk_merge(int device_id, const float* scores, const int64_t* ids, int32_t n_parts, int32_t nq,
+                             int32_t k, float* out_scores, int64_t* out_ids, void* stream) {
+    if (!scores || !ids || !out_scores || !out_ids || n_parts <= 0 || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
+    VRCHK(set_dev(device_id));
+    HIPCHK(launch_topk_merge(scores, ids, n_parts, nq, k, out_scores, out_ids, (hipStream_t)stream));
+    return VR_OK;
+}
+
+// ------------------------------------------------------------------------------ op-level ---
+extern "C" int vr_op_gemm(int device_id, const void* A, int32_t lda, const void* W, int32_t ldw, int32_t M, int32_t N,
+                          int32_t K, int32_t epilogue, const float* bias, const float* resid, float alpha, void* out,
+                          int32_t ldo, const int32_t* rope_pos, const float* rope_table, int32_t rope_cols,
+                          int32_t variant, void* stream) {
+    if (!A || !W || !out) return fail(VR_ERR_INVALID, "NULL argument");
+    if (N % 128 || K % 64 || M <= 0) return fail(VR_ERR_INVALID, "need N %% 128 == 0, K %% 64 == 0");
+    if (epilogue == EPI_RESID && !resid) return fail(VR_ERR_INVALID, "EPI_RESID needs resid");
+    if (epilogue == EPI_ROPE && (!rope_pos || !rope_table)) return fail(VR_ERR_INVALID, "EPI_ROPE needs tables");
+    VRCHK(set_dev(device_id));
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid;
+    a.alpha = alpha; a.out = out; a.ldo = ldo; a.rope_pos = rope_pos; a.rope_table = rope_table; a.rope_cols = rope_cols;
+    HIPCHK(launch_gemm(a, epilogue, variant, (hipStream_t)stream));
+    return VR_OK;
+}
+
+extern "C" int vr_op_norm(int device_id, int32_t kind, const float* x, int32_t rows, int32_t dim, const float* weight,
+                          const float* bias, float eps, void* out, int32_t ldo, void* stream) {
+    if (!x || !weight || !out || (kind == 0 && !bias)) return fail(VR_ERR_INVALID, "NULL argument");
+    VRCHK(set_dev(device_id));
+    if (kind == 0) HIPCHK(launch_layernorm(x, rows, dim, dim, weight, bias, eps, out, ldo, (hipStream_t)stream));
+    else HIPCHK(launch_rmsnorm(x, rows, dim, dim, weight, eps, out, ldo, (hipStream_t)stream));
+    return VR_OK;
+}
+
+extern "C" int vr_op_attention(int device_id, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v,
+                               int32_t ldv, void* out, int32_t ldo, const int32_t* cu_q, const int32_t* cu_kv, int32_t B,
+                               int32_t heads, int32_t head_dim, int32_t max_q, int32_t causal, int32_t q_shared,
+                               float scale, void* stream) {
+    if (!q || !k || !v || !out || !cu_q || !cu_kv) return fail(VR_ERR_INVALID, "NULL argument");
+    VRCHK(set_dev(device_id));
+    AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo; a.cu_q = cu_q;
+    a.cu_kv = cu_kv; a.B = B; a.heads = heads; a.head_dim = head_dim; a.max_q = max_q; a.causal = causal;
+    a.q_shared = q_shared; a.scale = scale;
+    HIPCHK(launch_attention(a, (hipStream_t)stream));
+    return VR_OK;
+}

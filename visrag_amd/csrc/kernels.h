@@ -27,10 +27,10 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 
 // ---- norms (norm.hip) --------------------------------------------------------------------
-// x f32 [rows][dim] -> bf16 [rows][ldo]; columns [dim, ldo) are written as zero.
-hipError_t launch_layernorm(const float* x, int rows, int dim, const float* w, const float* b,
+// x f32 [rows][ldx] (dim used) -> bf16 [rows][ldo]; columns [dim, ldo) are written as zero.
+hipError_t launch_layernorm(const float* x, int rows, int dim, int ldx, const float* w, const float* b,
                             float eps, void* out, int ldo, hipStream_t s);
-hipError_t launch_rmsnorm(const float* x, int rows, int dim, const float* w, float eps,
+hipError_t launch_rmsnorm(const float* x, int rows, int dim, int ldx, const float* w, float eps,
                           void* out, int ldo, hipStream_t s);
 
 // ---- attention (attention.hip) -----------------------------------------------------------

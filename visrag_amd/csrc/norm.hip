@@ -11,7 +11,7 @@ namespace vr {
 constexpr int NORM_MAXV = 10;   // float4 per lane: rows up to 64*4*10 = 2560 columns
 
 template <bool RMS>
-__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int rows, int dim,
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int rows, int dim, int ldx,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ b, float eps,
                                                    bf16_t* __restrict__ out, int ldo) {
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = dim >> 2;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * dim);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * ldx);
     f32x4 v[NORM_MAXV];
     float s = 0.f;
 #pragma unroll
@@ -65,20 +65,20 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     }
 }
 
-hipError_t launch_layernorm(const float* x, int rows, int dim, const float* w, const float* b,
+hipError_t launch_layernorm(const float* x, int rows, int dim, int ldx, const float* w, const float* b,
                             float eps, void* out, int ldo, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    if (dim % 4 || ldo % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, w, b, eps,
+    if (dim % 4 || ldo % 4 || ldx % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo || dim > ldx) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, b, eps,
                        (bf16_t*)out, ldo);
     return hipGetLastError();
 }
 
-hipError_t launch_rmsnorm(const float* x, int rows, int dim, const float* w, float eps, void* out,
+hipError_t launch_rmsnorm(const float* x, int rows, int dim, int ldx, const float* w, float eps, void* out,
                           int ldo, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    if (dim % 4 || ldo % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, w,
+    if (dim % 4 || ldo % 4 || ldx % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo || dim > ldx) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w,
                        (const float*)nullptr, eps, (bf16_t*)out, ldo);
     return hipGetLastError();
 }

@@ -1,0 +1,222 @@
+"""Thin Python owners of the two C-ABI objects: the VisRAG-Ret encoder (`HipEncoder`) and the
+HBM-resident index (`HipIndex`).  torch tensors are used only as device-memory containers
+and for the current HIP stream; all arithmetic happens in libvisrag_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import VisRAGRetConfig
+from .preprocess import PreparedItem
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else 0
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.VisragHipError("no HIP device visible: visrag_amd has no CPU fallback")
+
+
+class HipEncoder:
+    """Device-resident VisRAG-Ret weights + workspace (vr_model_*)."""
+
+    def __init__(self, cfg: VisRAGRetConfig, device: int = 0, max_images: int = 32,
+                 max_patches: Optional[int] = None, max_tokens: int = 4096, max_seqs: int = 64):
+        _require_gpu()
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = int(device)
+        if max_patches is None:
+            g = cfg.scale_resolution // cfg.patch_size
+            max_patches = int(g * g * 1.1) + 8       # sliced pages reach ~1064 patches per slice
+        self.max_images, self.max_tokens, self.max_seqs = max_images, max_tokens, max_seqs
+        self._c = _lib.make_config(cfg, max_images, max_patches, max_tokens, max_seqs)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.vr_model_create(self.device, C.byref(self._c), C.byref(self._h)), "vr_model_create")
+        self.finalized = False
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.vr_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights --------------------------------------------------------------------------
+    def load_weight(self, name: str, t: torch.Tensor) -> None:
+        if t.dtype == torch.bfloat16:
+            dt = _lib.VR_DTYPE_BF16
+        else:
+            t = t.to(torch.float32)
+            dt = _lib.VR_DTYPE_F32
+        t = t.contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _lib.check(self.lib.vr_model_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape,
+                                                 t.dim(), dt, 1 if t.is_cuda else 0), f"load {name}")
+        self.finalized = False
+
+    def load_state_dict(self, items: Iterable[Tuple[str, torch.Tensor]]) -> None:
+        """items: (HF key, tensor) pairs — a dict's .items() or a generator (tensors may be
+        released by the caller as soon as the call returns)."""
+        if isinstance(items, dict):
+            items = items.items()
+        for name, t in items:
+            self.load_weight(name, t)
+        self.finalize()
+
+    def finalize(self) -> None:
+        _lib.check(self.lib.vr_model_finalize(self._h), "vr_model_finalize")
+        self.finalized = True
+
+    # ---- encode ---------------------------------------------------------------------------
+    def encode_items(self, items: Sequence[PreparedItem], device_slices: Optional[List[torch.Tensor]] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """items -> unit-norm embeddings [B, hidden] float32 on the device.
+        `device_slices`: optional uint8 HWC cuda tensors replacing the host slices of the items
+        (same order: item 0's slices first, ...)."""
+        cfg = self.cfg
+        B = len(items)
+        if B == 0:
+            raise ValueError("empty batch")
+        Q = cfg.query_num
+        seq = np.zeros(B + 1, dtype=np.int32)
+        for i, it in enumerate(items):
+            seq[i + 1] = seq[i] + len(it.input_ids)
+        ids = np.concatenate([np.asarray(it.input_ids, dtype=np.int32) for it in items])
+        slices: List = []
+        hw: List[int] = []
+        rows: List[np.ndarray] = []
+        for i, it in enumerate(items):
+            for k, s in enumerate(it.slices):
+                slices.append(s)
+                hw += [int(s.shape[0]), int(s.shape[1])]
+                r = np.full(Q, -1, dtype=np.int32)
+                if k < len(it.image_bound):       # bound k <-> slice k (scatter_ semantics)
+                    b0, b1 = it.image_bound[k]
+                    n = max(0, min(Q, b1 - b0))
+                    r[:n] = seq[i] + b0 + np.arange(n, dtype=np.int32)
+                rows.append(r)
+        n_slices = len(slices)
+        on_dev = 0
+        keep = []
+        if n_slices:
+            if device_slices is not None:
+                if len(device_slices) != n_slices:
+                    raise ValueError("device_slices must match the items' slices")
+                ptrs = (C.c_void_p * n_slices)(*[C.c_void_p(t.data_ptr()) for t in device_slices])
+                on_dev = 1
+            else:
+                keep = [np.ascontiguousarray(s, dtype=np.uint8) for s in slices]
+                ptrs = (C.c_void_p * n_slices)(*[C.c_void_p(a.ctypes.data) for a in keep])
+            hw_arr = (C.c_int32 * (2 * n_slices))(*hw)
+            vr = np.ascontiguousarray(np.concatenate(rows), dtype=np.int32)
+            vr_p = vr.ctypes.data_as(C.POINTER(C.c_int32))
+        else:
+            ptrs, hw_arr, vr_p = None, None, None
+        if out is None:
+            out = torch.empty((B, cfg.hidden_size), dtype=torch.float32, device=f"cuda:{self.device}")
+        _lib.check(self.lib.vr_encode(
+            self._h, ptrs, hw_arr, n_slices, on_dev,
+            ids.ctypes.data_as(C.POINTER(C.c_int32)), seq.ctypes.data_as(C.POINTER(C.c_int32)), B,
+            vr_p, C.c_void_p(out.data_ptr()), 1, C.c_void_p(_stream_ptr())), "vr_encode")
+        return out
+
+    # ---- debug taps -----------------------------------------------------------------------
+    def set_taps(self, on: bool) -> None:
+        _lib.check(self.lib.vr_model_set_taps(self._h, 1 if on else 0))
+
+    def tap(self, name: str, rows: int, cols: int) -> np.ndarray:
+        out = np.empty((rows, cols), dtype=np.float32)
+        _lib.check(self.lib.vr_model_tap(self._h, name.encode(), C.c_void_p(out.ctypes.data), rows, cols),
+                   f"tap {name}")
+        return out
+
+
+class HipIndex:
+    """HBM-resident embedding index (fp32 rows + a bf16 copy for the MFMA sweep)."""
+
+    def __init__(self, dim: int, capacity: int, device: int = 0):
+        _require_gpu()
+        self.lib = _lib.load()
+        self.dim, self.capacity, self.device = int(dim), int(capacity), int(device)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.vr_index_create(self.device, self.dim, self.capacity, C.byref(self._h)),
+                   "vr_index_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.vr_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = C.c_int64()
+        _lib.check(self.lib.vr_index_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def reset(self) -> None:
+        _lib.check(self.lib.vr_index_reset(self._h))
+
+    def add(self, reps) -> None:
+        if isinstance(reps, torch.Tensor):
+            t = reps.to(torch.float32).contiguous()
+            assert t.dim() == 2 and t.shape[1] == self.dim
+            _lib.check(self.lib.vr_index_add(self._h, C.c_void_p(t.data_ptr()), t.shape[0],
+                                             1 if t.is_cuda else 0, C.c_void_p(_stream_ptr())), "vr_index_add")
+        else:
+            a = np.ascontiguousarray(reps, dtype=np.float32)
+            assert a.ndim == 2 and a.shape[1] == self.dim
+            _lib.check(self.lib.vr_index_add(self._h, C.c_void_p(a.ctypes.data), a.shape[0], 0,
+                                             C.c_void_p(_stream_ptr())), "vr_index_add")
+
+    def search(self, queries, k: int):
+        """-> (scores [nq,k] f32, ids [nq,k] i64); torch cuda tensors in -> cuda tensors out,
+        numpy / cpu in -> numpy out."""
+        if isinstance(queries, torch.Tensor) and queries.is_cuda:
+            q = queries.to(torch.float32).contiguous()
+            nq = q.shape[0]
+            sc = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            ix = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _lib.check(self.lib.vr_index_search(self._h, C.c_void_p(q.data_ptr()), nq, k,
+                                                C.c_void_p(sc.data_ptr()), C.c_void_p(ix.data_ptr()), 1,
+                                                C.c_void_p(_stream_ptr())), "vr_index_search")
+            return sc, ix
+        q = np.ascontiguousarray(queries.numpy() if isinstance(queries, torch.Tensor) else queries,
+                                 dtype=np.float32)
+        nq = q.shape[0]
+        sc = np.empty((nq, k), dtype=np.float32)
+        ix = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self.lib.vr_index_search(self._h, C.c_void_p(q.ctypes.data), nq, k,
+                                            C.c_void_p(sc.ctypes.data), C.c_void_p(ix.ctypes.data), 0,
+                                            C.c_void_p(_stream_ptr())), "vr_index_search")
+        return sc, ix
+
+
+def topk_merge(scores: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[n_parts, nq, k] per-shard (score, global id) lists -> merged [nq, k] (device tensors)."""
+    _require_gpu()
+    lib = _lib.load()
+    n_parts, nq, k = scores.shape
+    scores = scores.contiguous().to(torch.float32)
+    ids = ids.contiguous().to(torch.int64)
+    os_ = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    oi = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    _lib.check(lib.vr_topk_merge(scores.device.index or 0, C.c_void_p(scores.data_ptr()), C.c_void_p(ids.data_ptr()),
+                                 n_parts, nq, k, C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()),
+                                 C.c_void_p(_stream_ptr())), "vr_topk_merge")
+    return os_, oi

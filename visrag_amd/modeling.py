@@ -1,0 +1,167 @@
+"""Drop-in for the reference's retrieval-model wrapper on the encode path.
+
+Mirrors src/openmatch/modeling/dense_retrieval_model.py:
+  * `DROutput` (q_reps / p_reps)                                   :30-36
+  * `DRModelForInference.build(model_args, ...)`                   :233-364, 387-391
+  * `forward(query=..., passage=..., **kwargs)` / `encode_query` /
+    `encode_passage`                                               :142-231, 393-408
+where `query` / `passage` are the batch dicts of inference.py:85-101 (`id`, `text`, `image`
+lists; extra keys are ignored) and kwargs carry `tokenizer` and `max_inp_length`.
+Pooling `wmean` + `normalize=True` (the published VisRAG-Ret setting, eval.sh:62-63) are
+fused into the device path; other poolings raise.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .config import VisRAGRetConfig, full_config
+from .engine import HipEncoder
+from .preprocess import PreparedItem, prepare_batch
+
+
+@dataclass
+class DROutput:
+    q_reps: Optional[torch.Tensor] = None
+    p_reps: Optional[torch.Tensor] = None
+    loss: Optional[torch.Tensor] = None
+    scores: Optional[torch.Tensor] = None
+
+
+class DRModelForInference:
+    """HIP-backed equivalent of openmatch's DRModelForInference for VisRAG-Ret."""
+
+    def __init__(self, cfg: VisRAGRetConfig, encoder: HipEncoder, pooling: str = "wmean",
+                 normalize: bool = True):
+        if pooling != "wmean":
+            raise ValueError("Unknown pooling type: {} (the HIP path fuses 'wmean')".format(pooling))
+        assert normalize == True, "Normalize must be true"   # dense_retrieval_model.py:222
+        self.cfg, self.encoder = cfg, encoder
+        self.pooling, self.normalize = pooling, normalize
+        self.micro_batch = encoder.max_seqs
+
+    # ---- construction -----------------------------------------------------------------------
+    @classmethod
+    def build(cls, model_args=None, cfg: Optional[VisRAGRetConfig] = None,
+              state_dict: Optional[Iterable[Tuple[str, torch.Tensor]]] = None, device: int = 0,
+              max_images: int = 32, max_tokens: int = 4096, max_seqs: int = 64, **_):
+        """`model_args` needs `.model_name_or_path` (a HF checkpoint dir with *.safetensors /
+        pytorch_model*.bin and config.json) unless `state_dict` is given; `.pooling` and
+        `.normalize` are honoured like the reference (arguments.py)."""
+        pooling = getattr(model_args, "pooling", "wmean") if model_args is not None else "wmean"
+        normalize = getattr(model_args, "normalize", True) if model_args is not None else True
+        path = getattr(model_args, "model_name_or_path", None) if model_args is not None else None
+        if cfg is None:
+            cfg = config_from_checkpoint(path) if path else full_config()
+        enc = HipEncoder(cfg, device=device, max_images=max_images, max_tokens=max_tokens, max_seqs=max_seqs)
+        if state_dict is None:
+            if not path:
+                raise ValueError("need model_args.model_name_or_path or state_dict")
+            state_dict = iter_checkpoint(path)
+        enc.load_state_dict(state_dict)
+        return cls(cfg, enc, pooling=pooling, normalize=normalize)
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    # ---- reference API ----------------------------------------------------------------------
+    def encode(self, items: Optional[Dict], is_query: bool = False, tokenizer=None,
+               max_inp_length: int = 2048, **_):
+        if items is None:
+            return None, None
+        if tokenizer is None:
+            raise ValueError("tokenizer is required (model(passage=batch, tokenizer=tok, ...))")
+        texts, images = list(items["text"]), list(items.get("image", [None] * len(items["text"])))
+        prepared = prepare_batch(texts, images, tokenizer, self.cfg, max_inp_length)
+        return None, self.encode_prepared(prepared)
+
+    def encode_prepared(self, prepared: List[PreparedItem]) -> torch.Tensor:
+        """Splits into micro-batches that fit the workspace (tokens / sequences)."""
+        enc = self.encoder
+        outs, cur, tok = [], [], 0
+        for it in prepared:
+            n = len(it.input_ids)
+            if n > enc.max_tokens:
+                raise ValueError(f"sequence of {n} tokens exceeds max_tokens={enc.max_tokens}")
+            if cur and (tok + n > enc.max_tokens or len(cur) >= enc.max_seqs):
+                outs.append(enc.encode_items(cur)); cur, tok = [], 0
+            cur.append(it); tok += n
+        if cur:
+            outs.append(enc.encode_items(cur))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def encode_passage(self, psg, **kwargs):
+        return self.encode(psg, is_query=False, **kwargs)
+
+    def encode_query(self, qry, **kwargs):
+        return self.encode(qry, is_query=True, **kwargs)
+
+    def forward(self, query: Optional[Dict] = None, passage: Optional[Dict] = None, **kwargs) -> DROutput:
+        _, q_reps = self.encode_query(query, **kwargs)
+        _, p_reps = self.encode_passage(passage, **kwargs)
+        return DROutput(q_reps=q_reps, p_reps=p_reps)
+
+    __call__ = forward
+
+
+@torch.no_grad()
+def encode(model: DRModelForInference, tokenizer, text_or_image_list) -> np.ndarray:
+    """Demo helper with the signature of visrag_scripts/demo/visrag_pipeline/utils.py:12-32."""
+    if isinstance(text_or_image_list[0], str):
+        batch = {"text": list(text_or_image_list), "image": [None] * len(text_or_image_list)}
+        out = model(query=batch, tokenizer=tokenizer).q_reps
+    else:
+        batch = {"text": [""] * len(text_or_image_list), "image": list(text_or_image_list)}
+        out = model(passage=batch, tokenizer=tokenizer).p_reps
+    return out.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ checkpoint plumbing ----
+def config_from_checkpoint(path: str) -> VisRAGRetConfig:
+    """config.json of a MiniCPM-V-2.0 / VisRAG-Ret checkpoint -> VisRAGRetConfig
+    (dense_retrieval_model.py:248-269 dispatches on the same file)."""
+    with open(os.path.join(path, "config.json")) as f:
+        j = json.load(f)
+    c = full_config()
+    c.hidden_size = j.get("hidden_size", c.hidden_size)
+    c.num_layers = j.get("num_hidden_layers", c.num_layers)
+    c.num_heads = j.get("num_attention_heads", c.num_heads)
+    c.intermediate_size = j.get("intermediate_size", c.intermediate_size)
+    c.vocab_size = j.get("vocab_size", c.vocab_size)
+    c.rms_norm_eps = j.get("rms_norm_eps", c.rms_norm_eps)
+    c.rope_theta = j.get("rope_theta", c.rope_theta)
+    c.scale_emb = j.get("scale_emb", c.scale_emb)
+    c.scale_depth = j.get("scale_depth", c.scale_depth)
+    c.query_num = j.get("query_num", c.query_num)
+    c.patch_size = j.get("patch_size", c.patch_size)
+    c.max_slice_nums = j.get("max_slice_nums", c.max_slice_nums)
+    c.scale_resolution = j.get("scale_resolution", c.scale_resolution)
+    c.slice_mode = j.get("slice_mode", c.slice_mode)
+    return c
+
+
+def iter_checkpoint(path: str):
+    """Yield (key, tensor) from *.safetensors (preferred) or pytorch_model*.bin shards."""
+    files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+    if files:
+        from safetensors import safe_open
+        for fn in files:
+            with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    yield k, f.get_tensor(k)
+        return
+    files = sorted(f for f in os.listdir(path) if f.startswith("pytorch_model") and f.endswith(".bin"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors / pytorch_model*.bin under {path}")
+    for fn in files:
+        sd = torch.load(os.path.join(path, fn), map_location="cpu", weights_only=True)
+        for k, v in sd.items():
+            yield k, v
