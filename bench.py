@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""bench.py — VisRAG-Ret corpus embedding + retrieval on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of synthetic input already resident in
+HBM: 32 page images (448x448x3 uint8) -> vr_encode (SigLIP ViT + resampler + MiniCPM-2B
+decoder + wmean pool + L2 norm) -> 32 fp32 embeddings appended to the HBM-resident index.
+Workload at N=1 = BASELINE.json configs[1] (bf16 encode, batch 32 pages); pages are sharded
+across ranks with no data-path collective (weak scaling).  The same JSON line also carries
+the retrieval half of the metric (configs[2]/[3]): 1k queries top-10 over a 100k-row index
+sharded over the N ranks, local fused search + ONE RCCL all-gather of [nq,k] + device merge.
+
+Full model dims, random-init (deterministic synthetic) weights, synthetic pages: there is no
+network for checkpoints or datasets.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
+QUERY_PREFIX = "Represent this query for retrieving relevant documents: "
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--index-rows", type=int, default=100_000)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--search-steps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pages", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = torch.distributed
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from PIL import Image
+    from visrag_amd.config import full_config
+    from visrag_amd.engine import HipEncoder, HipIndex
+    from visrag_amd.preprocess import prepare_batch
+    from visrag_amd.retriever import sharded_search
+    from visrag_amd.synth import iter_synth_weights, synth_pages, synth_queries
+    from visrag_amd.tokenizer import StandInTokenizer
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cfg = full_config()
+    B = args.batch
+    t0 = time.time()
+    enc = HipEncoder(cfg, device=local_rank, max_images=B, max_tokens=max(4096, B * 80), max_seqs=max(64, B))
+    enc.load_state_dict(iter_synth_weights(cfg, 0, device=dev))
+    log(f"[rank {rank}] weights ready in {time.time() - t0:.1f}s")
+    tok = StandInTokenizer(cfg.vocab_size)
+
+    # ---- synthetic page pool resident in HBM; rank r embeds pages r*pool .. (its shard)
+    pool = 2 * B
+    pages = synth_pages(pool, size=448, seed=0, first=rank * pool)
+    items = prepare_batch([""] * pool, [Image.fromarray(p) for p in pages], tok, cfg, 2048)
+    dev_pages = [torch.from_numpy(p).to(dev) for p in pages]
+    batches = [(items[i:i + B], dev_pages[i:i + B]) for i in range(0, pool, B)]
+    rows_local = (args.index_rows + world - 1) // world
+    index = HipIndex(cfg.hidden_size, rows_local + (args.steps + args.warmup + 2) * B, device=local_rank)
+    out = torch.empty((B, cfg.hidden_size), dtype=torch.float32, device=dev)
+
+    def step(i):
+        it, px = batches[i % len(batches)]
+        enc.encode_items(it, device_slices=px, out=out)
+        index.add(out)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    index.reset()
+    enc.set_profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = enc.get_profile()
+    enc.set_profile(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    pages_per_s = world * args.steps * B / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- retrieval: fill the shard to index_rows/world rows with synthetic unit-norm embeddings,
+    #      encode the text queries with the model, then time sharded search
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    have = len(index)
+    filler = torch.randn((rows_local - min(have, rows_local), cfg.hidden_size), generator=g, device=dev)
+    filler = filler / filler.norm(dim=1, keepdim=True)
+    if have > rows_local:
+        index.reset()
+        filler = torch.randn((rows_local, cfg.hidden_size), generator=g, device=dev)
+        filler = filler / filler.norm(dim=1, keepdim=True)
+    index.add(filler)
+    del filler
+    qtexts = [QUERY_PREFIX + q for q in synth_queries(args.queries, seed=0)]
+    qitems = prepare_batch(qtexts, [None] * len(qtexts), tok, cfg, 512)
+    barrier()
+    tq0 = time.perf_counter()
+    qreps = []
+    for lo in range(0, len(qitems), 64):
+        qreps.append(enc.encode_items(qitems[lo:lo + 64]))
+    Q = torch.cat(qreps)
+    barrier()
+    q_encode_s = time.perf_counter() - tq0
+    for _ in range(3):
+        sc, ids = sharded_search(index, Q, args.topk, id_offset=rank * rows_local)
+    barrier()
+    ts0 = time.perf_counter()
+    for _ in range(args.search_steps):
+        sc, ids = sharded_search(index, Q, args.topk, id_offset=rank * rows_local)
+    barrier()
+    ds = time.perf_counter() - ts0
+    tmax = torch.tensor([ds], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ds = float(tmax.item())
+    search_qps = args.queries * args.search_steps / ds
+    # event-timed local sweep (kernel time only, for the search roofline)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.search_steps):
+        index.search(Q, args.topk)
+    e1.record()
+    torch.cuda.synchronize()
+    sweep_ms = e0.elapsed_time(e1) / args.search_steps
+    search_flops = 2.0 * args.queries * len(index) * cfg.hidden_size
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel class (by event-bracketed time)
+    gemm_like = {k: v for k, v in prof.items() if k.startswith("vit_") and v["launches"] > 0}
+    dom = max(gemm_like, key=lambda k: gemm_like[k]["ms"])
+    d = prof[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    kernel_names = {"vit_qkv": "gemm_bf16_kernel<EPI_BF16,GLDS> (ViT qkv)",
+                    "vit_attn": "attention_kernel<72,2> (ViT self-attention)",
+                    "vit_proj": "gemm_bf16_kernel<EPI_RESID,GLDS> (ViT attn proj)",
+                    "vit_fc1": "gemm_bf16_kernel<EPI_GELU,GLDS> (ViT MLP fc1)",
+                    "vit_fc2": "gemm_bf16_kernel<EPI_RESID,GLDS> (ViT MLP fc2)"}
+    roofline = {"bound": "mfma", "kernel": kernel_names[dom], "achieved": round(achieved, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
+                "flops_per_launch": d["flops"] / d["launches"], "traffic": None}
+    phases = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                  "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()}
+    f_page = cfg.flops_page(1024, len(items[0].input_ids))
+    result = {
+        "metric": "page-images embedded/sec (VisRAG-Ret encode, 448x448, bf16 MFMA) "
+                  "+ queries/sec@top-10 over 100k-page index",
+        "value": round(pages_per_s, 2), "unit": "pages/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "VisRAG-Ret (SigLIP-so400m 26 blk + resampler + MiniCPM-2B 40 layers) bf16 "
+                               f"encode batch={B} page images 448x448 per GPU; index {args.index_rows} rows x 2304 "
+                               f"sharded {world} way(s), {args.queries} queries top-{args.topk}",
+                   "batch_per_gpu": B, "global_batch": B * world, "tokens_per_page": len(items[0].input_ids),
+                   "flops_per_page": f_page, "parallelism": f"dp{world} (pages sharded, no data-path collective)"},
+        "model_tflops": round(pages_per_s * f_page / 1e12 / world, 1),
+        "model_frac_of_mfma_peak": round(pages_per_s * f_page / 1e12 / world / PEAK_BF16_TFLOPS, 4),
+        "queries_per_sec": round(search_qps, 1),
+        "search": {"index_rows": args.index_rows, "rows_per_gpu": len(index), "queries": args.queries,
+                   "k": args.topk, "ms_per_search": round(ds / args.search_steps * 1e3, 3),
+                   "local_sweep_ms": round(sweep_ms, 3),
+                   "local_sweep_tflops": round(search_flops / (sweep_ms * 1e-3) / 1e12, 1),
+                   "local_sweep_frac_of_mfma_peak": round(search_flops / (sweep_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                   "index_GBps": round(len(index) * cfg.hidden_size * 2 / (sweep_ms * 1e-3) / 1e9, 1),
+                   "query_encode_per_sec": round(args.queries / q_encode_s, 1)},
+        "roofline": roofline,
+        "phases": phases,
+    }
+
+    # ---- CPU baseline: the oracle (fp32 restatement of the reference) on the host cores, rank 0, N=1
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import visrag_ret_oracle as O
+            tc = time.time()
+            W = {k: v.cpu() for k, v in iter_synth_weights(cfg, 0, device=dev)}
+            log(f"cpu weights in {time.time() - tc:.1f}s; threads={torch.get_num_threads()}")
+            n = args.cpu_pages
+            it = items[:n]
+            O.encode(W, cfg, [i.input_ids for i in it[:1]], [i.image_bound for i in it[:1]], [i.slices for i in it[:1]])
+            tc = time.perf_counter()
+            ref = O.encode(W, cfg, [i.input_ids for i in it], [i.image_bound for i in it], [i.slices for i in it])
+            cpu_s = time.perf_counter() - tc
+            got = enc.encode_items(it, device_slices=dev_pages[:n]).cpu()
+            cos = float((got * ref).sum(1).min())
+            # retrieval baseline: torch fp32 matmul + topk over the same index (dense_retriever.py:28-30)
+            Cc = torch.randn((20_000, cfg.hidden_size)); Cc = Cc / Cc.norm(dim=1, keepdim=True)
+            Qc = Q.cpu()
+            tc = time.perf_counter()
+            O.search_topk(Qc.numpy(), Cc.numpy(), args.topk)
+            cpu_search_s = time.perf_counter() - tc
+            result["cpu_baseline"] = {
+                "value": round(n / cpu_s, 3), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} pages 448x448 through oracle/visrag_ret_oracle.py (torch-CPU fp32 restatement of the "
+                          f"reference forward, full dims) in {cpu_s:.1f}s; search: 1k queries x 20k rows fp32 "
+                          f"matmul+topk in {cpu_search_s:.2f}s",
+                "queries_per_sec_100k_est": round(args.queries / (cpu_search_s * args.index_rows / 20_000), 1),
+                "parity_min_cosine_vs_gpu": round(cos, 6)}
+        except Exception as e:   # the baseline is informational; never lose the GPU numbers
+            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,21 @@ int vr_model_tap(vr_model_t m, const char* name, float* out, int64_t rows, int64
 /* Enable/disable recording of taps (off by default; costs device copies). */
 int vr_model_set_taps(vr_model_t m, int32_t enable);
 
+/* Per-kernel-class HIP-event timing on the launch stream (bench.py roofline fields).
+ * Enabling resets the counters.  total_flops is the ALGORITHMIC work of the launches
+ * (SURVEY.md section 8d formulas), total_ms the sum of their event-bracketed durations. */
+#define VR_PROF_VIT_QKV 0    /* gemm_bf16_kernel<EPI_BF16>  : qkv projection            */
+#define VR_PROF_VIT_ATTN 1   /* attention_kernel<72,2>      : ViT self-attention        */
+#define VR_PROF_VIT_PROJ 2   /* gemm_bf16_kernel<EPI_RESID> : attn out-projection       */
+#define VR_PROF_VIT_FC1 3    /* gemm_bf16_kernel<EPI_GELU>  : MLP fc1 + erf-GELU        */
+#define VR_PROF_VIT_FC2 4    /* gemm_bf16_kernel<EPI_RESID> : MLP fc2 + residual        */
+#define VR_PROF_RESAMPLER 5  /* whole resampler phase (several kernels)                 */
+#define VR_PROF_DECODER 6    /* whole 40-layer decoder phase (several kernels)          */
+#define VR_PROF_CLASSES 7
+int vr_model_set_profile(vr_model_t m, int32_t enable);
+int vr_model_get_profile(vr_model_t m, int32_t cls, double* total_ms, int64_t* launches,
+                         double* total_flops);
+
 /* ---- index: replaces torch.matmul + torch.topk over pickle shards -------------------- */
 /* Reference: _retrieve_one_shard / distributed_parallel_retrieve
  * (src/openmatch/retriever/dense_retriever.py:13-97); demo answer.py:26-35. */

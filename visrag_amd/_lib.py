@@ -48,6 +48,8 @@ SIGNATURES = {
                             C.POINTER(_i32), _i32, C.POINTER(_i32), _vp, _i32, _vp]),
     "vr_model_tap": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64]),
     "vr_model_set_taps": (C.c_int, [_vp, _i32]),
+    "vr_model_set_profile": (C.c_int, [_vp, _i32]),
+    "vr_model_get_profile": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "vr_index_create": (C.c_int, [C.c_int, _i32, _i64, C.POINTER(_vp)]),
     "vr_index_destroy": (C.c_int, [_vp]),
     "vr_index_reset": (C.c_int, [_vp]),

@@ -125,6 +125,11 @@ struct vr_model_s {
     DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact;
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
     std::map<std::string, Tap> taps;
+    // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
+    // stream, elapsed times summed lazily in vr_model_get_profile
+    bool prof_on = false;
+    struct ProfClass { std::vector<hipEvent_t> ev; size_t used = 0; double ms = 0, flops = 0; int64_t launches = 0; };
+    ProfClass prof[VR_PROF_CLASSES];
     // pinned host arena for the small per-call arrays (ids, offsets, row maps, image pointers):
     // async H2D copies read it after vr_encode returned, `arena_ev` marks when they have run.
     char* arena = nullptr; size_t arena_cap = 0, arena_used = 0;
@@ -135,7 +140,8 @@ static int arena_begin(vr_model_s* m, size_t need) {
     if (m->arena_pending) { HIPCHK(hipEventSynchronize(m->arena_ev)); m->arena_pending = false; }
     if (!m->arena_ev) HIPCHK(hipEventCreateWithFlags(&m->arena_ev, hipEventDisableTiming));
     if (m->arena_cap < need) {
-        if (m->arena) (void)hipHostFree(m->arena);
+        for (auto& pc : m->prof) for (hipEvent_t e : pc.ev) (void)hipEventDestroy(e);
+    if (m->arena) (void)hipHostFree(m->arena);
         m->arena = nullptr; m->arena_cap = 0;
         const size_t cap = std::max(need, (size_t)4 << 20);
         HIPCHK(hipHostMalloc((void**)&m->arena, cap, hipHostMallocDefault));
@@ -148,6 +154,35 @@ static void* arena_take(vr_model_s* m, size_t bytes) {
     void* p = m->arena + m->arena_used;
     m->arena_used += (bytes + 63) / 64 * 64;
     return p;
+}
+
+static int prof_begin(vr_model_s* m, int cls, hipStream_t s) {
+    if (!m->prof_on) return VR_OK;
+    auto& p = m->prof[cls];
+    if (p.used + 2 > p.ev.size()) {
+        for (int i = 0; i < 64; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); p.ev.push_back(e); }
+    }
+    HIPCHK(hipEventRecord(p.ev[p.used], s));
+    return VR_OK;
+}
+static int prof_end(vr_model_s* m, int cls, double flops, hipStream_t s) {
+    if (!m->prof_on) return VR_OK;
+    auto& p = m->prof[cls];
+    HIPCHK(hipEventRecord(p.ev[p.used + 1], s));
+    p.used += 2; p.launches += 1; p.flops += flops;
+    return VR_OK;
+}
+static int prof_collect(vr_model_s* m) {
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& p : m->prof) {
+        for (size_t i = 0; i + 1 < p.used; i += 2) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+            p.ms += ms;
+        }
+        p.used = 0;
+    }
+    return VR_OK;
 }
 
 static int set_dev(int dev) {
@@ -194,6 +229,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); l.ln1.v.free(); l.ln2.v.free(); }
     for (Vec* v : {&m->vit_nw, &m->vit_nb, &m->r_lnq_w, &m->r_lnq_b, &m->r_lnkv_w, &m->r_lnkv_b, &m->r_lnpost_w, &m->r_lnpost_b, &m->final_norm}) v->v.free();
     for (auto& g : m->grids) { g.second.vit_pos.free(); g.second.pos_k.free(); }
+    for (auto& pc : m->prof) for (hipEvent_t e : pc.ev) (void)hipEventDestroy(e);
     if (m->arena) (void)hipHostFree(m->arena);
     if (m->arena_ev) (void)hipEventDestroy(m->arena_ev);
     for (DevBuf* b : {&m->r_q, &m->embed, &m->rope, &m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
@@ -710,7 +746,9 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     for (int l = 0; l < c.vit_depth; ++l) {
         const VitBlock& b = m->blocks[l];
         HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
+        VRCHK(prof_begin(m, VR_PROF_VIT_QKV, s));
         { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_GLDS, s)); }
+        VRCHK(prof_end(m, VR_PROF_VIT_QKV, 2.0 * M * D * 3 * D, s));
         {
             AttnArgs a{};
             a.q = m->w_qkv.p; a.ldq = ldqkv;
@@ -718,18 +756,27 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
             a.v = (const char*)m->w_qkv.p + (size_t)2 * D * 2; a.ldv = ldqkv;
             a.out = m->w_att.p; a.ldo = Dp; a.cu_q = cu_tok; a.cu_kv = cu_tok; a.B = n; a.heads = c.vit_heads;
             a.head_dim = 72; a.max_q = N; a.causal = 0; a.q_shared = 0; a.scale = 1.0f / sqrtf(72.0f);
+            VRCHK(prof_begin(m, VR_PROF_VIT_ATTN, s));
             HIPCHK(launch_attention(a, s));
+            VRCHK(prof_end(m, VR_PROF_VIT_ATTN, 4.0 * n * (double)N * N * D, s));
         }
+        VRCHK(prof_begin(m, VR_PROF_VIT_PROJ, s));
         { GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        VRCHK(prof_end(m, VR_PROF_VIT_PROJ, 2.0 * M * D * D, s));
         HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
+        VRCHK(prof_begin(m, VR_PROF_VIT_FC1, s));
         { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_GLDS, s)); }
+        VRCHK(prof_end(m, VR_PROF_VIT_FC1, 2.0 * M * D * m->F, s));
+        VRCHK(prof_begin(m, VR_PROF_VIT_FC2, s));
         { GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        VRCHK(prof_end(m, VR_PROF_VIT_FC2, 2.0 * M * D * m->F, s));
         if (l == 0 && first_group) VRCHK(tap_store(m, "vit_block0", h, N, D, Dp, false, s));
     }
     HIPCHK(launch_layernorm(h, M, D, Dp, m->vit_nw.v.as<float>(), m->vit_nb.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
     if (first_group) VRCHK(tap_store(m, "vit_out", m->w_xn.p, N, D, Dp, true, s));
 
     // ---- resampler (resampler.py:146-168)
+    VRCHK(prof_begin(m, VR_PROF_RESAMPLER, s));
     { GemmArgs a = gemm_args(m->w_xn.p, Dp, m->r_kvproj, M, m->w_kv32.p, E); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s)); }
     HIPCHK(launch_layernorm(m->w_kv32.as<float>(), M, E, E, m->r_lnkv_w.v.as<float>(), m->r_lnkv_b.v.as<float>(),
                             c.resampler_ln_eps, m->w_xkv.p, E, s));
@@ -760,6 +807,7 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         a.rowmap = m->w_rowmap.as<int>();
         HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s));
     }
+    VRCHK(prof_end(m, VR_PROF_RESAMPLER, 2.0 * M * D * E + 4.0 * M * E * (double)E + 4.0 * R * (double)N * E + 4.0 * R * E * (double)E, s));
     return VR_OK;
 }
 
@@ -853,6 +901,7 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
     int max_len = 0;
     for (int i = 0; i < B; ++i) max_len = std::max(max_len, seq_offsets[i + 1] - seq_offsets[i]);
     if (max_len > m->rope_len) return fail(VR_ERR_CAPACITY, "sequence of %d tokens exceeds the RoPE table", max_len);
+    VRCHK(prof_begin(m, VR_PROF_DECODER, s));
     for (int l = 0; l < c.num_layers; ++l) {
         const DecLayer& L = m->layers[l];
         HIPCHK(launch_rmsnorm(h, T, E, E, L.ln1.v.as<float>(), c.rms_norm_eps, m->w_dxn.p, E, s));
@@ -875,6 +924,12 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
         { GemmArgs a = gemm_args(m->w_dact.p, m->Ip, L.down, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
         if (l == 0) VRCHK(tap_store(m, "dec_layer0", h, T, E, E, false, s));
     }
+    {
+        double fl = 0;
+        for (int i = 0; i < B; ++i) { const double Li = seq_offsets[i + 1] - seq_offsets[i]; fl += 4.0 * Li * Li * E; }
+        fl = c.num_layers * (fl + (double)T * (8.0 * E * E + 6.0 * (double)E * m->I));
+        VRCHK(prof_end(m, VR_PROF_DECODER, fl, s));
+    }
     // ---- K19+K20: final norm + wmean pool + L2 normalise
     float* tap_hidden = nullptr;   // scratch f32 [T][E] for the post-norm hidden states
     if (m->taps_on && (size_t)T * E * 4 <= m->w_kv32.bytes) tap_hidden = m->w_kv32.as<float>();
@@ -885,6 +940,24 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
     m->arena_pending = true;
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out_reps, dst, (size_t)B * E * 4, hipMemcpyDeviceToHost, s));
     if (!out_on_device || (n_slices > 0 && !slices_on_device)) HIPCHK(hipStreamSynchronize(s));   // host buffers consumed
+    return VR_OK;
+}
+
+extern "C" int vr_model_set_profile(vr_model_t m, int32_t enable) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    VRCHK(set_dev(m->device));
+    VRCHK(prof_collect(m));
+    m->prof_on = enable != 0;
+    for (auto& p : m->prof) { p.ms = 0; p.flops = 0; p.launches = 0; p.used = 0; }
+    return VR_OK;
+}
+
+extern "C" int vr_model_get_profile(vr_model_t m, int32_t cls, double* total_ms, int64_t* launches, double* total_flops) {
+    if (!m || cls < 0 || cls >= VR_PROF_CLASSES || !total_ms || !launches || !total_flops)
+        return fail(VR_ERR_INVALID, "bad profile arguments");
+    VRCHK(set_dev(m->device));
+    VRCHK(prof_collect(m));
+    *total_ms = m->prof[cls].ms; *launches = m->prof[cls].launches; *total_flops = m->prof[cls].flops;
     return VR_OK;
 }
 

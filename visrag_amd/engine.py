@@ -131,6 +131,20 @@ class HipEncoder:
             vr_p, C.c_void_p(out.data_ptr()), 1, C.c_void_p(_stream_ptr())), "vr_encode")
         return out
 
+    # ---- profiling (HIP events around kernel classes, see include/visrag_hip.h) -------------
+    PROF_CLASSES = ("vit_qkv", "vit_attn", "vit_proj", "vit_fc1", "vit_fc2", "resampler", "decoder")
+
+    def set_profile(self, on: bool) -> None:
+        _lib.check(self.lib.vr_model_set_profile(self._h, 1 if on else 0))
+
+    def get_profile(self) -> Dict[str, Dict[str, float]]:
+        out = {}
+        for i, name in enumerate(self.PROF_CLASSES):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            _lib.check(self.lib.vr_model_get_profile(self._h, i, C.byref(ms), C.byref(n), C.byref(fl)))
+            out[name] = {"ms": ms.value, "launches": int(n.value), "flops": fl.value}
+        return out
+
     # ---- debug taps -----------------------------------------------------------------------
     def set_taps(self, on: bool) -> None:
         _lib.check(self.lib.vr_model_set_taps(self._h, 1 if on else 0))
