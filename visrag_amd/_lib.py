@@ -75,6 +75,11 @@ def load(path: Optional[str] = None) -> C.CDLL:
         raise VisragHipError(
             f"{p} not found: the HIP extension is not built. Run `python -m visrag_amd.build` "
             "(or __graft_entry__.build()); there is no CPU fallback.")
+    # torch wheels bundle their own ROCm runtime (torch/lib/libamdhip64.so).  It must be the
+    # ONE HIP runtime of the process: import torch first so that our DT_NEEDED libamdhip64.so.7
+    # binds to the already-loaded copy (loading ours first would pull /opt/rocm's runtime in and
+    # give torch a second one — streams and device pointers would not be shared).
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
