@@ -8,46 +8,56 @@
 //        valid row because causal already hides keys > query)
 //
 // One workgroup = 4 waves = QF*64 query rows of one (batch item, head); KV tiles of 64 keys
-// staged through LDS; online softmax in fp32.  Both matmuls are TRANSPOSED so that the
-// softmax statistics and P never leave registers:
-//   S^T[key][q] = K * Q^T     (mfma A = K fragment from LDS, B = Q fragment kept in VGPRs)
-//   O^T[d][q]  += V^T * P^T   (mfma A = V^T fragment from LDS, B = P^T = the S^T accumulator
-//                              itself, re-packed to bf16 — the C layout of the first MFMA is
-//                              a valid B layout of the second for a permuted key order, and
-//                              V^T is stored in LDS in that same permuted order)
-// A lane therefore owns one query column (q = lane & 15): max / sum are 16 in-lane values
-// plus a 2-step cross-lane reduction, and the final O row is 4 consecutive d per lane
-// (8-byte stores).  head_dim 72 is zero-padded to 96 for QK^T and to 80 for PV.
+// staged ROW-MAJOR through LDS (16-byte writes); online softmax in fp32.  Both matmuls are
+// TRANSPOSED so that the softmax statistics and P never leave registers:
+//   S^T[key][q] = K * Q^T     (mfma A = K fragment, ds_read_b128; B = Q fragment kept in VGPRs)
+//   O^T[d][q]  += V^T * P^T   (mfma A = V^T fragment, fetched with ds_read_b64_tr_b16 — the
+//                              gfx950 transposing LDS read — straight from the row-major V
+//                              tile; B = P^T = the S^T accumulator itself re-packed to bf16:
+//                              the C layout of the first MFMA is a valid B layout of the second
+//                              for the key order (2ks*16 + g*4 + j | (2ks+1)*16 + g*4 + j), and
+//                              the two tr-reads of a V fragment fetch exactly those keys)
+// A lane therefore owns one query column (q = lane & 15): max / sum are 16 in-lane values plus
+// a 2-step cross-lane reduction, and the final O row is 4 consecutive d per lane (8-byte stores).
+// head_dim 72: QK^T = 2 x (16x16x32) + 1 x (16x16x16) MFMA (d padded to 80 with zeros in LDS),
+// PV = 5 d-fragments (80).  Row pitch 160 B (288 B for head_dim 128) = 8 mod 64 dwords makes
+// both the b128 K reads and the tr_b16 V reads bank-conflict free.
 // Roofline: MFMA (4*N^2*D flop per head).
 #include "common.h"
 #include "kernels.h"
 
+#ifndef VR_ATTN_TAIL_X16
+#define VR_ATTN_TAIL_X16 0
+#endif
+
 namespace vr {
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
 template <int HD> struct AttnCfg;
-template <> struct AttnCfg<64>  { static constexpr int KSTEPS = 2, DFRAGS = 4, KPITCH = 128; };
-template <> struct AttnCfg<72>  { static constexpr int KSTEPS = 3, DFRAGS = 5, KPITCH = 256; };
-template <> struct AttnCfg<128> { static constexpr int KSTEPS = 4, DFRAGS = 8, KPITCH = 256; };
+template <> struct AttnCfg<64>  { static constexpr int K32 = 2, TAIL = 0, DFRAGS = 4, PITCH = 160; };
+template <> struct AttnCfg<72>  { static constexpr int K32 = 2, TAIL = 1, DFRAGS = 5, PITCH = 160; };
+template <> struct AttnCfg<128> { static constexpr int K32 = 4, TAIL = 0, DFRAGS = 8, PITCH = 288; };
 
 constexpr int ATT_KV = 64;          // keys per tile
 
-// position of key `key` (0..63) inside a V^T row: MFMA k-slot order of the PV product
-__device__ __forceinline__ int vt_slot(int key) {
-    return (key & 32) | (((key >> 2) & 3) << 3) | (((key >> 4) & 1) << 2) | (key & 3);
+__device__ __forceinline__ bf16x4 lds_tr_read(const char* p) {
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(bf16x4, r);
 }
 
 template <int HD, int QF>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     using C = AttnCfg<HD>;
-    constexpr int KSTEPS = C::KSTEPS, DFRAGS = C::DFRAGS, KPITCH = C::KPITCH;
-    constexpr int KCH = KPITCH / 16;              // 16-byte chunks per K row in LDS
+    constexpr int K32 = C::K32, DFRAGS = C::DFRAGS, PITCH = C::PITCH;
+    constexpr bool TAIL = C::TAIL != 0;
     constexpr int CPR = HD / 8;                   // 16-byte chunks per global row
     constexpr int QT = 64 * QF;                   // query rows per workgroup
     constexpr int NCH = (ATT_KV * CPR + 255) / 256;   // staging chunks per thread
 
-    __shared__ __attribute__((aligned(16))) char smem[ATT_KV * KPITCH + DFRAGS * 16 * 128];
+    __shared__ __attribute__((aligned(16))) char smem[2 * ATT_KV * PITCH];
     char* Ks = smem;
-    char* Vt = smem + ATT_KV * KPITCH;
+    char* Vs = smem + ATT_KV * PITCH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -67,22 +77,27 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     const bf16_t* kbase = (const bf16_t*)p.k + (size_t)kv0 * p.ldk + h * HD;
     const bf16_t* vbase = (const bf16_t*)p.v + (size_t)kv0 * p.ldv + h * HD;
 
-    // ---- zero the LDS padding that staging never overwrites (K pad columns, V^T pad rows)
+    // ---- zero the LDS row padding once (staging never overwrites it)
     for (int i = tid; i < (int)sizeof(smem) / 16; i += 256)
         reinterpret_cast<u32x4*>(smem)[i] = u32x4{0, 0, 0, 0};
 
     // ---- Q fragments (B operand of S^T): lane holds Q[q = fr][d = ks*32 + fq*8 .. +7]
-    bf16x8 qf[QF][KSTEPS];
+    bf16x8 qf[QF][K32];
+    bf16x4 qtail[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         const int q = qs + (wave * QF + f) * 16 + fr;
+        const bool ok = q < q_len;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int d = ks * 32 + fq * 8;
+        for (int ks = 0; ks < K32; ++ks) {
             u32x4 raw = {0, 0, 0, 0};
-            if (q < q_len && d < HD) raw = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + d);
+            if (ok) raw = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + ks * 32 + fq * 8);
             qf[f][ks] = __builtin_bit_cast(bf16x8, raw);
         }
+        u32x2 rt = {0, 0};
+        if (TAIL && ok && K32 * 32 + fq * 4 < HD)
+            rt = *reinterpret_cast<const u32x2*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 4);
+        qtail[f] = __builtin_bit_cast(bf16x4, rt);
     }
 
     f32x4 o[QF][DFRAGS];
@@ -99,38 +114,36 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     const int n_tiles = (kv_end + ATT_KV - 1) / ATT_KV;
     const float sc = p.scale * 1.44269504088896340736f;   // exp2 domain
 
+    // Staging: every thread moves NCH 16-byte chunks of K and of V per tile.  Loads are
+    // UNCONDITIONAL (row clamped to the last valid key): a load under a divergent branch makes
+    // hipcc drain vmcnt(0) at the join and lose the prefetch.  Rows past kv_len are therefore
+    // copies of the last key — harmless, their scores are masked to -inf (P = 0).
     u32x4 rk[NCH], rv[NCH];
+    int st_key[NCH], st_ch[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = min(tid + i * 256, ATT_KV * CPR - 1);
+        st_key[i] = c / CPR; st_ch[i] = c % CPR;
+    }
     auto load_tile = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * 256;
-            const int key = c / CPR, ch = c % CPR;
-            const int kg = tile * ATT_KV + key;
-            rk[i] = u32x4{0, 0, 0, 0}; rv[i] = u32x4{0, 0, 0, 0};
-            if (c < ATT_KV * CPR && kg < kv_len) {
-                rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kg * p.ldk + ch * 8);
-                rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)kg * p.ldv + ch * 8);
-            }
+            const int kg = min(tile * ATT_KV + st_key[i], kv_len - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kg * p.ldk + st_ch[i] * 8);
+            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)kg * p.ldv + st_ch[i] * 8);
         }
     };
     auto write_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + i * 256;
-            if (c >= ATT_KV * CPR) continue;
-            const int key = c / CPR, ch = c % CPR;
-            // K row-major, chunk XOR-swizzled: conflict-free ds_read_b128 of the A fragments
-            *reinterpret_cast<u32x4*>(Ks + key * KPITCH + ((ch ^ (key & (KCH - 1))) << 4)) = rk[i];
-            // V transposed: Vt[d][slot(key)], 8-chunk rows swizzled by (d & 7)
-            const int pos = vt_slot(key);
-            const bf16x8 vv = __builtin_bit_cast(bf16x8, rv[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = ch * 8 + e;
-                *reinterpret_cast<bf16_t*>(Vt + d * 128 + ((((pos >> 3) ^ (d & 7)) << 4) | ((pos & 7) << 1))) = vv[e];
-            }
+        for (int i = 0; i < NCH; ++i) {   // (threads clamped to the last chunk rewrite the same bytes)
+            *reinterpret_cast<u32x4*>(Ks + st_key[i] * PITCH + st_ch[i] * 16) = rk[i];
+            *reinterpret_cast<u32x4*>(Vs + st_key[i] * PITCH + st_ch[i] * 16) = rv[i];
         }
     };
+
+    // per-lane LDS offsets: K rows by fragment, V tr-read base (row fq*4 + fr/4, col-quad fr%4)
+    const int k_off = fr * PITCH + fq * 16;
+    const int v_off = (fq * 4 + (fr >> 2)) * PITCH + (fr & 3) * 8;
 
     load_tile(0);
     for (int tile = 0; tile < n_tiles; ++tile) {
@@ -140,47 +153,87 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
         if (tile + 1 < n_tiles) load_tile(tile + 1);   // in flight during the MFMAs below
 
         const int key0 = tile * ATT_KV;
+        // ---- S^T = K Q^T : all K fragments of the tile are fetched up front (each read once for
+        //      all QF q-fragments), so the LDS latency is paid once and the MFMAs run back to back
+        bf16x8 ka[4][K32];
+        bf16x4 kt[4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            const char* kr = Ks + kf * 16 * PITCH + k_off;
+#pragma unroll
+            for (int ks = 0; ks < K32; ++ks) ka[kf][ks] = *reinterpret_cast<const bf16x8*>(kr + ks * 64);
+            if constexpr (TAIL) kt[kf] = *reinterpret_cast<const bf16x4*>(Ks + (kf * 16 + fr) * PITCH + K32 * 64 + fq * 8);
+        }
+        f32x4 s[QF][4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < K32; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kf][ks], qf[f][ks], acc, 0, 0, 0);
+                if constexpr (TAIL) {
+#if VR_ATTN_TAIL_X16
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt[kf], qtail[f], acc, 0, 0, 0);
+#else
+                    const bf16x4 z = {};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(kt[kf], z, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                  __builtin_shufflevector(qtail[f], z, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                  acc, 0, 0, 0);
+#endif
+                }
+                s[f][kf] = acc;
+            }
+        }
+        // V^T fragments of the first PV k-step: issued now, consumed after the softmax below
+        bf16x8 va0[DFRAGS];
+#pragma unroll
+        for (int d = 0; d < DFRAGS; ++d) {
+            const char* vr = Vs + v_off + d * 32;
+            va0[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        // ---- mask + online softmax; lane owns query q, keys key0 + kf*16 + fq*4 + r
+        const bool need_mask = (key0 + ATT_KV > kv_len) || (p.causal && key0 + ATT_KV > qs);
+        bf16x8 pb[QF][2];
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
-            // ---- S^T = K Q^T : 4 key fragments x KSTEPS
-            f32x4 s[4];
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf) {
-                s[kf] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int row = kf * 16 + fr;
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const bf16x8 ka = *reinterpret_cast<const bf16x8*>(
-                        Ks + row * KPITCH + (((ks * 4 + fq) ^ (row & (KCH - 1))) << 4));
-                    s[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[f][ks], s[kf], 0, 0, 0);
-                }
-            }
-            // ---- mask + online softmax; this lane: query q, keys key0 + kf*16 + fq*4 + r
-            const int q = qs + (wave * QF + f) * 16 + fr;
-            const int lim = p.causal ? min(kv_len - 1, q) : kv_len - 1;   // last visible key
             float mx = -INFINITY;
+            if (need_mask) {
+                const int q = qs + (wave * QF + f) * 16 + fr;
+                const int lim = p.causal ? min(kv_len - 1, q) : kv_len - 1;   // last visible key
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
+                for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + kf * 16 + fq * 4 + r;
-                    const float v = (key <= lim) ? s[kf][r] * sc : -INFINITY;
-                    s[kf][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + kf * 16 + fq * 4 + r;
+                        const float v = (key <= lim) ? s[f][kf][r] * sc : -INFINITY;
+                        s[f][kf][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            } else {
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = s[f][kf][r] * sc;
+                        s[f][kf][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[f], mx);
             // rows with no visible key so far keep m = -inf; use 0 there so exp2(-inf - 0) = 0
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m_run[f] - m_use);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);
             float rs = 0.f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[kf][r] - m_use);
-                    s[kf][r] = e;
+                    const float e = __builtin_amdgcn_exp2f(s[f][kf][r] - m_use);
+                    s[f][kf][r] = e;
                     rs += e;
                 }
             rs += __shfl_xor(rs, 16, 64);
@@ -189,24 +242,32 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
             m_run[f] = m_new;
 #pragma unroll
             for (int d = 0; d < DFRAGS; ++d) o[f][d] *= alpha;
-            // ---- O^T += V^T P^T : P^T fragment for k-step ks = S^T fragments (2ks, 2ks+1)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pb;
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pb[r] = f2bf(s[2 * ks][r]);
-                    pb[4 + r] = f2bf(s[2 * ks + 1][r]);
+                    pb[f][ks][r] = f2bf(s[f][2 * ks][r]);
+                    pb[f][ks][4 + r] = f2bf(s[f][2 * ks + 1][r]);
                 }
-#pragma unroll
-                for (int d = 0; d < DFRAGS; ++d) {
-                    const int row = d * 16 + fr;
-                    const bf16x8 va = *reinterpret_cast<const bf16x8*>(
-                        Vt + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
-                    o[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[f][d], 0, 0, 0);
-                }
-            }
         }
+        // ---- O^T += V^T P^T : each V^T fragment (two transposing reads; rows (2ks)*16 + fq*4 + j
+        //      and (2ks+1)*16 + fq*4 + j) feeds all QF q-fragments
+        bf16x8 va1[DFRAGS];
+#pragma unroll
+        for (int d = 0; d < DFRAGS; ++d) {
+            const char* vr = Vs + v_off + 32 * PITCH + d * 32;
+            va1[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int d = 0; d < DFRAGS; ++d)
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+                o[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0[d], pb[f][0], o[f][d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < DFRAGS; ++d)
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+                o[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1[d], pb[f][1], o[f][d], 0, 0, 0);
     }
 
     // ---- normalise and store: lane owns out[q][h*HD + d*16 + fq*4 .. +3]
