@@ -1,0 +1,140 @@
+"""CPU-only host-logic tests: C-ABI symbols, on-disk formats, slicing policy, loud failure
+without a GPU, and the world_size-2 (gloo) sharded-retrieval merge."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from visrag_amd import _lib
+from visrag_amd.preprocess import slice_image, choose_grid, find_best_resize
+from visrag_amd.retriever import merge_topk_host
+from visrag_amd import utils as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/visrag_hip.h is the contract: every `vr_*` it declares must be exported by the
+    built library and bound by the ctypes table (no compute calls here: no GPU)."""
+    hdr = open(os.path.join(ROOT, "include", "visrag_hip.h")).read()
+    declared = set(re.findall(r"\b(vr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.vr_version().startswith(b"visrag_hip")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_no_silent_cpu_fallback():
+    from visrag_amd.config import tiny_config
+    from visrag_amd.engine import HipEncoder, HipIndex
+    with pytest.raises(_lib.VisragHipError):
+        HipEncoder(tiny_config())
+    with pytest.raises(_lib.VisragHipError):
+        HipIndex(64, 10)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under visrag_amd/ may import or exec it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|importlib[^\n]*oracle|open\([^\n]*oracle/", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "visrag_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f
+
+
+def test_slicing_policy_examples():
+    """Sizes the survey probed on the reference's slice_image."""
+    from PIL import Image
+    def plan(w, h):
+        src, patches, grid = slice_image(Image.new("RGB", (w, h)), 9, 448, 14)
+        return src.size, grid, (patches[0][0].size if patches else None), sum(len(r) for r in patches)
+    assert plan(448, 448) == ((448, 448), None, None, 0)
+    assert plan(1114, 1670) == ((364, 546), [2, 4], (518, 392), 8)
+    assert plan(1654, 2339) == ((378, 532), [3, 3], (378, 532), 9)
+    assert plan(2160, 1790)[1] == [3, 3] and plan(1072, 670)[1] == [2, 2] and plan(564, 3040)[1] == [1, 8]
+    assert choose_grid((448, 448), 9, 448) is None
+
+
+def test_trec_and_shard_formats(tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, "retrieve.npz"))
+    qids = [str(q) for q in g["qids"]]
+    run = {q: {str(d): float(s) for d, s in zip(g["docs"][i], g["scores"][i])} for i, q in enumerate(qids)}
+    p = tmp_path / "out" / "test.0.trec"
+    U.save_as_trec(run, str(p))
+    assert open(p).read() == str(g["trec"])            # byte-identical to the reference's writer
+    back = U.load_from_trec(str(p))
+    assert back.keys() == run.keys() and all(abs(back[q][d] - run[q][d]) < 1e-9 for q in run for d in run[q])
+    reps = np.arange(12, dtype=np.float32).reshape(3, 4)
+    sp = tmp_path / U.shard_name("corpus", 1, 0, 3)
+    U.write_shard(str(sp), reps, ["a", "b", "c"])
+    r2, ids = U.read_shard(str(sp))
+    assert np.array_equal(r2, reps) and ids == ["a", "b", "c"] and sp.name == "embeddings.corpus.rank.1.0-3"
+    qrel = {qids[0]: {str(g["docs"][0][1]): 1}}
+    assert abs(U.eval_mrr(qrel, {qids[0]: run[qids[0]]}, 10) - 0.5) < 1e-9
+    nd, rc = U.ndcg_recall_at_k(qrel, run, 10)
+    assert rc == 1.0 and abs(nd - 1.0 / np.log2(3)) < 1e-9
+
+
+def test_merge_rule_equals_global_topk():
+    """Sharding rows over P parts, taking local top-k and merging == global top-k (the
+    invariant the multi-GPU path relies on)."""
+    from oracle import visrag_ret_oracle as O
+    rng = np.random.default_rng(0)
+    C = rng.standard_normal((1000, 32)).astype(np.float32)
+    Q = rng.standard_normal((9, 32)).astype(np.float32)
+    C[500] = C[20]                                      # cross-shard exact tie
+    k, P = 10, 4
+    per = 250
+    parts_s, parts_i = [], []
+    for r in range(P):
+        s, i = O.search_topk(Q, C[r * per:(r + 1) * per], k)
+        parts_s.append(s); parts_i.append(i + r * per)
+    ms, mi = merge_topk_host(np.stack(parts_s), np.stack(parts_i), k)
+    gs, gi = O.search_topk(Q, C, k)
+    assert np.array_equal(mi, gi) and np.allclose(ms, gs)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["VR_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from oracle import visrag_ret_oracle as O
+from visrag_amd.retriever import merge_topk_host
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["VR_PORT"],
+                        rank=int(os.environ["VR_RANK"]), world_size=2)
+rank = dist.get_rank()
+rng = np.random.default_rng(0)
+C = rng.standard_normal((400, 16)).astype(np.float32); Q = rng.standard_normal((5, 16)).astype(np.float32)
+lo = rank * 200
+s, i = O.search_topk(Q, C[lo:lo + 200], 7)            # local shard search (CPU stand-in for HipIndex)
+ts, ti = torch.from_numpy(s.copy()), torch.from_numpy(i + lo)
+gs = [torch.empty_like(ts) for _ in range(2)]; gi = [torch.empty_like(ti) for _ in range(2)]
+dist.all_gather(gs, ts); dist.all_gather(gi, ti)       # the one exchange step of the path
+ms, mi = merge_topk_host(torch.stack(gs).numpy(), torch.stack(gi).numpy(), 7)
+rs, ri = O.search_topk(Q, C, 7)
+assert np.array_equal(mi, ri) and np.allclose(ms, rs), rank
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_retrieval_world2_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): shard -> local top-k -> all_gather -> merge == global."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, VR_ROOT=ROOT, VR_PORT=str(port), VR_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
