@@ -7,5 +7,8 @@ if which == "gemm":
     print(json.dumps(bench_gemm(32768, 4352, 1152, 1)))
     print(json.dumps(bench_gemm(32768, 1152, 4352, 3)))
     print(json.dumps(bench_gemm(8192, 8192, 8192, 0)))
+elif which == "occ":
+    for v in (0, 0x100):
+        print(json.dumps(bench_gemm(100096, 1024, 2304, 0, v)))
 else:
     print(json.dumps(bench_attn()))

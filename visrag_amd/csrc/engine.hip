@@ -966,7 +966,7 @@ struct vr_index_s {
     int device = 0, dim = 0;
     int64_t cap = 0, n = 0;
     DevBuf f32, bf16;                 // [cap_pad][dim]
-    DevBuf q32, qbf, cs, ci, os, oi;  // query staging / candidates / outputs
+    DevBuf q32, qbf, cs, ci, os, oi, thr;  // query staging / candidates / outputs / thresholds
     int64_t qcap = 0, ccap = 0;
 };
 
@@ -989,7 +989,7 @@ extern "C" int vr_index_destroy(vr_index_t ix) {
     if (!ix) return VR_OK;
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->os, &ix->oi}) b->free();
+    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->os, &ix->oi, &ix->thr}) b->free();
     delete ix;
     return VR_OK;
 }
@@ -1032,6 +1032,7 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
     if (ix->qcap < nqp) {
         VRCHK(ix->q32.alloc((size_t)nqp * dim * 4));
         VRCHK(ix->qbf.alloc((size_t)nqp * dim * 2));
+        VRCHK(ix->thr.alloc((size_t)nqp * 4));
         ix->qcap = nqp;
     }
     const float* q32 = queries;
@@ -1058,7 +1059,8 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
         a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
         a.q_bf16 = ix->qbf.p; a.q_f32 = q32; a.nq = nq; a.k = k;
         a.n_chunks = search_num_chunks(ix->n, nq);
-        const int64_t need = nqp * a.n_chunks * kp;
+        a.thr_init = ix->thr.as<float>();
+        const int64_t need = nqp * std::max(a.n_chunks, 8) * kp;
         if (ix->ccap < need) {
             VRCHK(ix->cs.alloc((size_t)need * 4));
             VRCHK(ix->ci.alloc((size_t)need * 4));

@@ -103,6 +103,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 template <int EPI>
 static hipError_t launch_epi(const GemmArgs& a, int variant, hipStream_t s) {
     const int tiles = (a.N / GEMM_BN) * ((a.M + GEMM_BM - 1) / GEMM_BM);
+    if (variant == 0x100) {   // experiment: same kernel at 1 workgroup per CU (130 KiB of LDS requested)
+        auto k = gemm_bf16_kernel<EPI, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024);
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), 130 * 1024, s, a);
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES);
+        return hipGetLastError();
+    }
     if (variant == GEMM_VARIANT_REG) {
         auto k = gemm_bf16_kernel<EPI, false>;
         static bool attr = false;

@@ -80,8 +80,13 @@ struct SweepLds {
 };
 constexpr int SWEEP_SMEM = GEMM_SMEM_BYTES + (int)sizeof(SweepLds);
 
+// tile_step > 1 is the threshold PRE-PASS: each chunk visits one tile, tiles spread evenly over
+// the index; its per-query KP-th best score (search_thr_kernel) is a valid lower bound of the
+// global KP-th best and seeds the thresholds of the main sweep, which then rejects ~98 % of the
+// scores in registers from its first tile on (no per-chunk warm-up of sorts).
 template <int KP>
-__global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk) {
+__global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk,
+                                                           int tile_step, const float* __restrict__ thr_init) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SweepLds& L = *reinterpret_cast<SweepLds*>(smem + GEMM_SMEM_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,9 +98,15 @@ __global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_t
     const int q0 = qt * 128;
     const int n_tiles = (int)((p.n_docs + 127) / 128);
     const int tile_lo = chunk * tiles_per_chunk;
-    const int tile_hi = min(n_tiles, tile_lo + tiles_per_chunk);
+    const int tile_hi = min((n_tiles + tile_step - 1) / tile_step, tile_lo + tiles_per_chunk);
 
-    if (tid < 128) { L.thr[tid] = -INFINITY; L.cnt[tid] = 0; }
+    if (tid < 128) {
+        // padding queries (zero rows, every score ties at 0) must never collect candidates
+        float t0 = thr_init ? thr_init[q0 + tid] : -INFINITY;
+        if (q0 + tid >= p.nq) t0 = INFINITY;
+        L.thr[tid] = t0;
+        L.cnt[tid] = 0;
+    }
     __syncthreads();
 
     // one wave compacts the buffers of its 32 queries: sort, keep the best KP, raise thr
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_t
     };
 
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
-        const int doc0 = tile * 128;
+        const int doc0 = tile * tile_step * 128;
         gemm_acc_t acc;
         gemm_zero(acc);
         gemm_mainloop<true>(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim,
@@ -166,6 +177,28 @@ __global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_t
             p.cand_ids[o] = -1;
         }
     }
+}
+
+// pre-pass result -> per-query initial threshold: the KP-th best score over the sampled tiles
+// (or -inf when the sample holds fewer than KP rows)
+template <int KP>
+__global__ __launch_bounds__(256) void search_thr_kernel(SearchArgs p, int n_chunks_pre, int nq_pad,
+                                                         float* __restrict__ thr) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq_pad) return;
+    const int total = n_chunks_pre * KP;
+    const float* cs = p.cand_scores + (size_t)q * total;
+    const int* ci = p.cand_ids + (size_t)q * total;
+    uint64_t best = KEY_NONE;
+    for (int base = 0; base < total; base += 64) {
+        const int e = base + lane;
+        uint64_t key = KEY_NONE;
+        if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
+        best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
+    }
+    const uint64_t kth = shfl_u64(best, KP - 1);
+    if (lane == 0) thr[q] = (kth == KEY_NONE) ? -INFINITY : orderable_f32((uint32_t)(kth >> 32));
 }
 
 constexpr int MERGE_MAXV = 10;
@@ -236,17 +269,32 @@ int search_num_chunks(int64_t n_docs, int nq) {
     return chunks;
 }
 
+constexpr int PRE_CHUNKS = 8;      // pre-pass: 8 sampled tiles = 1024 rows
+
 template <int KP>
 static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     const int q_tiles = (a.nq + 127) / 128;
     const int n_tiles = (int)((a.n_docs + 127) / 128);
-    const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
     auto k = search_sweep_kernel<KP>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEP_SMEM); attr = true; }
-    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    const float* thr = nullptr;
+    if (a.thr_init && n_tiles >= 8 * PRE_CHUNKS) {
+        SearchArgs pre = a;
+        pre.n_chunks = PRE_CHUNKS;
+        const int step = n_tiles / PRE_CHUNKS;
+        hipLaunchKernelGGL(k, dim3(PRE_CHUNKS * q_tiles), dim3(256), SWEEP_SMEM, s, pre, q_tiles, 1, step,
+                           (const float*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(search_thr_kernel<KP>, dim3(q_tiles * 32), dim3(256), 0, s, pre, PRE_CHUNKS, q_tiles * 128,
+                           a.thr_init);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        thr = a.thr_init;
+    }
+    const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
+    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc, 1, thr);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(search_merge_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
