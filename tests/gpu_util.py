@@ -10,7 +10,7 @@ def P(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def pad_rows(t, mult=128):
+def pad_rows(t, mult=256):
     r = (t.shape[0] + mult - 1) // mult * mult
     if r == t.shape[0]:
         return t.contiguous()

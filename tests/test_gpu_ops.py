@@ -23,8 +23,8 @@ def _rand(shape, seed, scale=1.0):
 
 
 # ------------------------------------------------------------------------------- GEMM ---
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1024, 384, 640), (77, 128, 2304)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (300, 256, 192), (1024, 512, 640), (77, 256, 2304), (700, 768, 128)])
 def test_gemm_bias_bf16(M, N, K, variant):
     A, W, b = _bf(_rand((M, K), 1)), _bf(_rand((N, K), 2, 0.1)), _rand((N,), 3)
     ref = A.float() @ W.float().T + b
@@ -44,7 +44,7 @@ def test_gemm_identity_asymmetric():
     np.testing.assert_allclose(out.numpy(), _bf(W).float().T[:100].numpy(), rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
 def test_gemm_epilogues(variant):
     M, N, K = 200, 256, 128
     A, W, b = _bf(_rand((M, K), 4)), _bf(_rand((N, K), 5, 0.2)), _rand((N,), 6)
@@ -69,9 +69,10 @@ def test_gemm_epilogues(variant):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
 
 
-def test_gemm_rope():
+@pytest.mark.parametrize("variant", [0, 2, 4, 5, 6])
+def test_gemm_rope(variant):
     """EPI_ROPE == apply_rotary_pos_emb (modeling_minicpm.py:259-290) on q,k columns; v untouched."""
-    M, E, K = 150, 128, 128            # 2 heads of 64; N = 3E
+    M, E, K = 150, 256, 128            # 4 heads of 64; N = 3E
     A, W = _bf(_rand((M, K), 8)), _bf(_rand((3 * E, K), 9, 0.2))
     pos = torch.arange(M, dtype=torch.int32) % 50
     inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
@@ -86,7 +87,8 @@ def test_gemm_rope():
             x1, x2 = x[:, :32], x[:, 32:]
             ref[:, part * E + h * 64: part * E + h * 64 + 32] = x1 * c - x2 * s
             ref[:, part * E + h * 64 + 32: part * E + (h + 1) * 64] = x2 * c + x1 * s
-    out = op_gemm(A.to(DEV), W.to(DEV), 5, rope_pos=pos.to(DEV), rope_table=table.to(DEV), rope_cols=2 * E).float().cpu()
+    out = op_gemm(A.to(DEV), W.to(DEV), 5, rope_pos=pos.to(DEV), rope_table=table.to(DEV), rope_cols=2 * E,
+                  variant=variant).float().cpu()
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
 
 

@@ -48,6 +48,8 @@ static int fail(int code, const char* fmt, ...) {
 
 static inline int pad128(int x) { return (x + 127) / 128 * 128; }
 static inline int64_t pad128l(int64_t x) { return (x + 127) / 128 * 128; }
+static inline int pad256(int x) { return (x + 255) / 256 * 256; }
+static inline int64_t pad256l(int64_t x) { return (x + 255) / 256 * 256; }
 
 extern "C" const char* vr_version(void) { return "visrag_hip 0.1.0 (gfx950)"; }
 extern "C" const char* vr_last_error(void) { return g_err.c_str(); }
@@ -259,7 +261,7 @@ static int load_linear_part(Linear& L, int n_total, int k, const void* dev_src, 
                             int transpose, int blk, int blk_stride, int blk_off) {
     if (!L.w.p) {
         L.n = n_total; L.k = k; L.n_pad = pad128(n_total); L.k_pad = pad128(k);
-        VRCHK(L.w.alloc((size_t)L.n_pad * L.k_pad * 2));
+        VRCHK(L.w.alloc((size_t)pad256(n_total) * L.k_pad * 2));   // rows readable by a 256-row tile
     } else if (L.n != n_total || L.k != k) {
         return fail(VR_ERR_INVALID, "inconsistent shapes for a packed weight");
     }
@@ -270,7 +272,7 @@ static int load_linear_part(Linear& L, int n_total, int k, const void* dev_src, 
 }
 
 static int load_bias_part(Linear& L, int n_total, const void* dev_src, int is_bf16, int rows, int off) {
-    if (!L.b.p) VRCHK(L.b.alloc((size_t)pad128(n_total) * 4));
+    if (!L.b.p) VRCHK(L.b.alloc((size_t)pad256(n_total) * 4));
     HIPCHK(launch_to_f32(dev_src, is_bf16, L.b.as<float>() + off, rows, 0));
     HIPCHK(hipDeviceSynchronize());
     L.has_b = true;
@@ -516,9 +518,9 @@ static GemmArgs gemm_args(const void* A, int lda, const Linear& L, int M, void* 
 
 static int alloc_workspace(vr_model_s* m) {
     const vr_config_t& c = m->c;
-    const int64_t M = pad128l((int64_t)c.max_images * c.max_patches);
-    const int64_t T = pad128l(c.max_tokens);
-    const int64_t R = pad128l((int64_t)c.max_images * m->Q);
+    const int64_t M = pad256l((int64_t)c.max_images * c.max_patches);
+    const int64_t T = pad256l(c.max_tokens);
+    const int64_t R = pad256l((int64_t)c.max_images * m->Q);
     m->Mcap = M; m->Tcap = T; m->Rcap = R;
     const int E = m->E, Dp = m->Dp;
     VRCHK(m->w_im2col.alloc((size_t)M * m->Kpe_p * 2));
@@ -739,7 +741,7 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     {
         GemmArgs a = gemm_args(m->w_im2col.p, m->Kpe_p, m->patch, M, h, Dp);
         a.rowbias = g->vit_pos.as<float>(); a.rowbias_period = N; a.rowbias_ld = Dp; a.rowbias_cols = Dp;
-        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s));
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s));
     }
     if (first_group) VRCHK(tap_store(m, "vit_embed", h, N, D, Dp, false, s));
     const int ldqkv = pad128(3 * D);
@@ -747,7 +749,7 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         const VitBlock& b = m->blocks[l];
         HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_QKV, s));
-        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_QKV, 2.0 * M * D * 3 * D, s));
         {
             AttnArgs a{};
@@ -761,14 +763,14 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
             VRCHK(prof_end(m, VR_PROF_VIT_ATTN, 4.0 * n * (double)N * N * D, s));
         }
         VRCHK(prof_begin(m, VR_PROF_VIT_PROJ, s));
-        { GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_PROJ, 2.0 * M * D * D, s));
         HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC1, s));
-        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_FC1, 2.0 * M * D * m->F, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC2, s));
-        { GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_FC2, 2.0 * M * D * m->F, s));
         if (l == 0 && first_group) VRCHK(tap_store(m, "vit_block0", h, N, D, Dp, false, s));
     }
@@ -777,13 +779,13 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
 
     // ---- resampler (resampler.py:146-168)
     VRCHK(prof_begin(m, VR_PROF_RESAMPLER, s));
-    { GemmArgs a = gemm_args(m->w_xn.p, Dp, m->r_kvproj, M, m->w_kv32.p, E); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s)); }
+    { GemmArgs a = gemm_args(m->w_xn.p, Dp, m->r_kvproj, M, m->w_kv32.p, E); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s)); }
     HIPCHK(launch_layernorm(m->w_kv32.as<float>(), M, E, E, m->r_lnkv_w.v.as<float>(), m->r_lnkv_b.v.as<float>(),
                             c.resampler_ln_eps, m->w_xkv.p, E, s));
     {   // fused k|v in-projection; the k half gets the per-position term pos_k[row % N]
         GemmArgs a = gemm_args(m->w_xkv.p, E, m->r_kv, M, m->w_KV.p, 2 * E);
         a.rowbias = g->pos_k.as<float>(); a.rowbias_period = N; a.rowbias_ld = E; a.rowbias_cols = E;
-        HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_GLDS, s));
+        HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s));
     }
     {
         AttnArgs a{};
@@ -793,19 +795,19 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         HIPCHK(launch_attention(a, s));
     }
     const int R = n * Q;
-    { GemmArgs a = gemm_args(m->w_ratt.p, E, m->r_out, R, m->w_rout.p, E); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s)); }
+    { GemmArgs a = gemm_args(m->w_ratt.p, E, m->r_out, R, m->w_rout.p, E); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s)); }
     HIPCHK(launch_layernorm(m->w_rout.as<float>(), R, E, E, m->r_lnpost_w.v.as<float>(), m->r_lnpost_b.v.as<float>(),
                             c.resampler_ln_eps, m->w_rln.p, E, s));
     if (first_group && m->taps_on) {   // un-scattered copy for the tap
         GemmArgs a = gemm_args(m->w_rln.p, E, m->r_proj, Q, m->w_rout.p, E);
-        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s));
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s));
         VRCHK(tap_store(m, "resampler_out", m->w_rout.p, Q, E, E, false, s));
     }
     {   // x @ proj, scattered straight into the decoder's fp32 input rows (image_bound scatter_,
         // modeling_minicpmv.py:148-166; vision rows are NOT scaled by scale_emb)
         GemmArgs a = gemm_args(m->w_rln.p, E, m->r_proj, R, m->w_h.p, E);
         a.rowmap = m->w_rowmap.as<int>();
-        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_GLDS, s));
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s));
     }
     VRCHK(prof_end(m, VR_PROF_RESAMPLER, 2.0 * M * D * E + 4.0 * M * E * (double)E + 4.0 * R * (double)N * E + 4.0 * R * E * (double)E, s));
     return VR_OK;
@@ -908,7 +910,7 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
         {
             GemmArgs a = gemm_args(m->w_dxn.p, E, L.qkv, T, m->w_dqkv.p, 3 * E);
             a.rope_pos = m->w_pos.as<int>(); a.rope_table = m->rope.as<float>(); a.rope_cols = 2 * E;
-            HIPCHK(launch_gemm(a, EPI_ROPE, GEMM_VARIANT_GLDS, s));
+            HIPCHK(launch_gemm(a, EPI_ROPE, GEMM_VARIANT_AUTO, s));
         }
         {
             AttnArgs a{};
@@ -918,10 +920,10 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
             a.max_q = max_len; a.causal = 1; a.q_shared = 0; a.scale = 1.0f / sqrtf(64.0f);
             HIPCHK(launch_attention(a, s));
         }
-        { GemmArgs a = gemm_args(m->w_datt.p, E, L.o, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_datt.p, E, L.o, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
         HIPCHK(launch_rmsnorm(h, T, E, E, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_dxn.p, E, s));
-        { GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_GLDS, s)); }
-        { GemmArgs a = gemm_args(m->w_dact.p, m->Ip, L.down, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s)); }
+        { GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
+        { GemmArgs a = gemm_args(m->w_dact.p, m->Ip, L.down, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
         if (l == 0) VRCHK(tap_store(m, "dec_layer0", h, T, E, E, false, s));
     }
     {

@@ -7,7 +7,9 @@ namespace vr {
 
 // ---- GEMM (gemm.hip) ---------------------------------------------------------------------
 enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_SWIGLU = 4, EPI_ROPE = 5 };
-enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1 };
+// GLDS/REG: 128x128 tile (LDS-DMA / register staging); 256: 256x256 8-wave tile (needs W and A
+// readable up to the next multiple of 256 rows); AUTO picks by M.
+enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1, GEMM_VARIANT_256 = 2, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_256P4 = 4, GEMM_VARIANT_256MID = 5, GEMM_VARIANT_256STAG = 6 };
 
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M_pad][lda]
@@ -23,6 +25,7 @@ struct GemmArgs {
     const int* rope_pos;             // EPI_ROPE: position of row m
     const float* rope_table;         // f32 [max_pos][64] = cos[32] | sin[32]
     int rope_cols;                   // columns < rope_cols are rotated (q and k), rest copied (v)
+    int raster_gm;                   // 256-tile kernels: m-tiles per raster group (0 = choose by W size)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 
