@@ -40,6 +40,7 @@ template <> struct AttnCfg<72>  { static constexpr int K32 = 2, TAIL = 1, DFRAGS
 template <> struct AttnCfg<128> { static constexpr int K32 = 4, TAIL = 0, DFRAGS = 8, PITCH = 288; };
 
 constexpr int ATT_KV = 64;          // keys per tile
+constexpr float MAX_SLACK = 8.0f;   // log2 units the running max may lag behind before O is rescaled
 
 __device__ __forceinline__ bf16x4 lds_tr_read(const char* p) {
     const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -80,6 +81,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     // ---- zero the LDS row padding once (staging never overwrites it)
     for (int i = tid; i < (int)sizeof(smem) / 16; i += 256)
         reinterpret_cast<u32x4*>(smem)[i] = u32x4{0, 0, 0, 0};
+
+    if constexpr (TAIL) {   // V column HD (= 72) := 1.0 in every key row: the PV MFMA then also yields the row sums
+        __syncthreads();
+        if (tid < ATT_KV) *reinterpret_cast<bf16_t*>(Vs + tid * PITCH + HD * 2) = (bf16_t)1.0f;
+    }
 
     // ---- Q fragments (B operand of S^T): lane holds Q[q = fr][d = ks*32 + fq*8 .. +7]
     bf16x8 qf[QF][K32];
@@ -193,55 +199,54 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             const char* vr = Vs + v_off + d * 32;
             va0[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        // ---- mask + online softmax; lane owns query q, keys key0 + kf*16 + fq*4 + r
+        // ---- mask + online softmax; lane owns query q, keys key0 + kf*16 + fq*4 + r.
+        // VALU diet (the kernel is VALU/MFMA balanced at head_dim 72): the scale is folded into one
+        // fma per score, the running max is only raised when it grows by more than 2^MAX_SLACK
+        // (so the O rescale is a rare wave-uniform branch; P stays <= 2^MAX_SLACK, harmless in
+        // bf16/fp32), and for head_dim 72 the row sum comes out of the PV MFMA itself: column 72 of
+        // the zero-padded V tile holds 1.0, so O^T[72][q] = sum_k P[k][q].
         const bool need_mask = (key0 + ATT_KV > kv_len) || (p.causal && key0 + ATT_KV > qs);
         bf16x8 pb[QF][2];
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
-            float mx = -INFINITY;
             if (need_mask) {
                 const int q = qs + (wave * QF + f) * 16 + fr;
                 const int lim = p.causal ? min(kv_len - 1, q) : kv_len - 1;   // last visible key
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = key0 + kf * 16 + fq * 4 + r;
-                        const float v = (key <= lim) ? s[f][kf][r] * sc : -INFINITY;
-                        s[f][kf][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-            } else {
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = s[f][kf][r] * sc;
-                        s[f][kf][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + kf * 16 + fq * 4 + r > lim) s[f][kf][r] = -INFINITY;
             }
+            float mx = fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3]));
+#pragma unroll
+            for (int kf = 1; kf < 4; ++kf)
+                mx = fmaxf(mx, fmaxf(fmaxf(s[f][kf][0], s[f][kf][1]), fmaxf(s[f][kf][2], s[f][kf][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[f], mx);
-            // rows with no visible key so far keep m = -inf; use 0 there so exp2(-inf - 0) = 0
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);
-            float rs = 0.f;
+            const float mxs = mx * sc;
+            const bool upd = mxs > m_run[f] + MAX_SLACK;       // (-inf + slack = -inf: first valid tile updates)
+            if (__any(upd)) {
+                const float m_new = upd ? mxs : m_run[f];
+                const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[f] - m_new);
+                m_run[f] = m_new;
+                if constexpr (!TAIL) l_run[f] *= alpha;
+#pragma unroll
+                for (int d = 0; d < DFRAGS; ++d) o[f][d] *= alpha;
+            }
+            const float neg_m = (m_run[f] == -INFINITY) ? 0.f : -m_run[f];   // all-masked rows: exp2(-inf) = 0
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[f][kf][r] - m_use);
-                    s[f][kf][r] = e;
-                    rs += e;
-                }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            l_run[f] = l_run[f] * alpha + rs;
-            m_run[f] = m_new;
+                for (int r = 0; r < 4; ++r) s[f][kf][r] = __builtin_amdgcn_exp2f(fmaf(s[f][kf][r], sc, neg_m));
+            if constexpr (!TAIL) {
+                float rs = 0.f;
 #pragma unroll
-            for (int d = 0; d < DFRAGS; ++d) o[f][d] *= alpha;
+                for (int kf = 0; kf < 4; ++kf) rs += (s[f][kf][0] + s[f][kf][1]) + (s[f][kf][2] + s[f][kf][3]);
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[f] += rs;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -274,8 +279,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         const int q = qs + (wave * QF + f) * 16 + fr;
+        float l = l_run[f];
+        if constexpr (TAIL) l = __shfl(o[f][DFRAGS - 1][0], 32 + fr, 64);   // O^T[72][q]: lane (fq=2, fr=q), reg 0 (all lanes active here)
         if (q >= q_len) continue;
-        const float inv = 1.0f / l_run[f];
+        const float inv = 1.0f / l;
         bf16_t* orow = (bf16_t*)p.out + (size_t)(q_row0 + q) * p.ldo + h * HD;
 #pragma unroll
         for (int d = 0; d < DFRAGS; ++d) {
