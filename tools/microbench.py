@@ -76,6 +76,10 @@ if __name__ == "__main__":
             res.append(bench_gemm(M, 4352, 1152, 1, v))
             res.append(bench_gemm(M, 1152, 4352, 3, v))
             res.append(bench_gemm(M, 1152, 1152, 3, v))
+        res.append(bench_gemm(M, 1152, 4352, 3, 7))
+        res.append(bench_gemm(M, 1152, 1152, 3, 7))
+        res.append(bench_gemm(M, 1152, 1152, 0, 7))
+        res.append(bench_gemm(M, 1152, 1152, 0, 0))
         res.append(bench_gemm(2176, 6912, 2304, 0))
         res.append(bench_gemm(2176, 11520, 2304, 4))
         res.append(bench_gemm(2176, 2304, 5760, 3))

@@ -9,94 +9,10 @@
 #include "gemm_core_mid.h"
 #include "gemm_core_stag.h"
 #include "kernels.h"
+#include "gemm_epilogue.h"
 #include <cstdlib>
 
 namespace vr {
-
-// nn.GELU() default = exact erf form (timm mlp.py / vision_transformer.py:466), NOT the tanh
-// approximation.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
-// rounding of the output): 1 rcp + 1 exp + 6 fma instead of libm erff's ~30 instructions, which
-// cost the fc1 GEMM a quarter of its throughput.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-poly * t, e, 1.0f);          // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
-
-// Epilogue of one 16-row fragment strip: this lane holds out[m][nb + j*16 + fq*4 + r], j = 0..3.
-// `nb` is the first of the wave's 64 output columns.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_row(f32x4 (&acc)[4], const GemmArgs& p, int m, int nb, int fq) {
-    if (m >= p.M) return;
-    const int orow = p.rowmap ? p.rowmap[m] : m;
-    if (orow < 0) return;
-    if constexpr (EPI == EPI_SWIGLU) {
-        // W rows are interleaved in blocks of 16: [16 gate | 16 up | ...]; fragment j even is
-        // gate, j odd is up, for the same 16 output columns.
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            if (nb + jj * 32 >= p.N) continue;
-            const int oc = nb / 2 + jj * 16 + fq * 4;
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(acc[2 * jj][r]) * acc[2 * jj + 1][r]);
-            *reinterpret_cast<bf16x4*>((bf16_t*)p.out + (size_t)orow * p.ldo + oc) = o;
-        }
-    } else if constexpr (EPI == EPI_ROPE) {
-        // the wave's 64 columns are exactly one head (head_dim 64): rotate-half pairs (c, c+32)
-        // live in fragments (j, j+2) of the same lane.  fp32, like apply_rotary_pos_emb
-        // (modeling_minicpm.py:259-290); table = [pos][32 cos | 32 sin].
-        if (nb >= p.N) return;
-        if (nb < p.rope_cols) {
-            const float* tab = p.rope_table + (size_t)p.rope_pos[m] * 64;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 cs = *reinterpret_cast<const f32x4*>(tab + j * 16 + fq * 4);
-                const f32x4 sn = *reinterpret_cast<const f32x4*>(tab + 32 + j * 16 + fq * 4);
-                const f32x4 x1 = acc[j], x2 = acc[j + 2];
-                acc[j] = x1 * cs - x2 * sn;
-                acc[j + 2] = x2 * cs + x1 * sn;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = nb + j * 16 + fq * 4;
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[j][r]);
-            *reinterpret_cast<bf16x4*>((bf16_t*)p.out + (size_t)orow * p.ldo + n) = o;
-        }
-    } else {
-        const float* rb = nullptr;
-        if (p.rowbias) rb = p.rowbias + (size_t)(m % p.rowbias_period) * p.rowbias_ld;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = nb + j * 16 + fq * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[j];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(EPI == EPI_GELU ? gelu_erf(v[r]) : v[r]);
-                *reinterpret_cast<bf16x4*>((bf16_t*)p.out + (size_t)orow * p.ldo + n) = o;
-            } else if constexpr (EPI == EPI_F32) {
-                *reinterpret_cast<f32x4*>((float*)p.out + (size_t)orow * p.ldo + n) = v;
-            } else {   // EPI_RESID: out = resid + alpha * (acc + bias); may alias resid
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (size_t)orow * p.ldo + n);
-                *reinterpret_cast<f32x4*>((float*)p.out + (size_t)orow * p.ldo + n) = rs + p.alpha * v;
-            }
-        }
-    }
-}
 
 template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
@@ -186,7 +102,11 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
+    if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_AUTO) {
+        // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel
+        if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID)
+            return launch_gemm192(a, epi, s);
         // 256x256 tiles when M is big enough to fill the chip with them and N is a multiple of 256
         // or wide enough that one partial tile column costs little (3456 -> 14 tiles, +3.7 %);
         // N = 1152 (4.5 tiles) stays on the 128x128 kernel (measured: 806 vs 771 TF).
