@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    if constexpr (EPI == EPI_RESID) {
+        if (!p.rowmap) { gemm_epilogue_resid_tile<4, 4, 4>(acc, p, m0 + wm * 64 + (lane & 15), n0 + wn * 64, lane >> 4); return; }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         gemm_epilogue_row<EPI>(acc[i], p, m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64, lane >> 4);
@@ -60,6 +63,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 2, wn = wave & 3;
+    if constexpr (EPI == EPI_RESID) {
+        if (!p.rowmap) { gemm_epilogue_resid_tile<8, 4, 4>(acc, p, m0 + wm * 128 + (lane & 15), n0 + wn * 64, lane >> 4); return; }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         gemm_epilogue_row<EPI>(acc[i], p, m0 + wm * 128 + i * 16 + (lane & 15), n0 + wn * 64, lane >> 4);

@@ -87,9 +87,13 @@ __global__ __launch_bounds__(512, 2) void gemm192_bf16_kernel(GemmArgs p) {
             __builtin_amdgcn_s_setprio(0);
         }
     }
+    if constexpr (EPI == EPI_RESID) {
+        gemm_epilogue_resid_tile<4, 6, 4>(acc, p, m0 + wm * 64 + fr, n0 + wn * 96, fq);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        gemm_epilogue_row<EPI, 6>(acc[i], p, m0 + wm * 64 + i * 16 + fr, n0 + wn * 96, fq);
+        for (int i = 0; i < 4; ++i)
+            gemm_epilogue_row<EPI, 6>(acc[i], p, m0 + wm * 64 + i * 16 + fr, n0 + wn * 96, fq);
+    }
 }
 
 template <int EPI>

@@ -92,3 +92,52 @@ __device__ __forceinline__ void gemm_epilogue_row(f32x4 (&acc)[NF], const GemmAr
 }
 
 }  // namespace vr
+
+namespace vr {
+
+// Residual epilogue for a whole wave tile: out = resid + alpha * (acc + bias), fp32, in place.
+// All residual fragments of a chunk are LOADED FIRST with unconditional (row/column-clamped)
+// addresses, then combined and stored under a predicate.  The per-row version above puts each
+// row's loads behind a divergent `m < M` branch, so hipcc drains vmcnt(0) at every join and the
+// fp32 read-modify-write of the residual stream (8 B/element, the epilogue's whole cost) runs
+// with one row of loads in flight; here MI_CH x NF 16-byte loads are in flight per lane.
+template <int MI, int NF, int MI_CH>
+__device__ __forceinline__ void gemm_epilogue_resid_tile(f32x4 (&acc)[MI][NF], const GemmArgs& p, int mrow0,
+                                                         int nb, int fq) {
+    static_assert(MI % MI_CH == 0, "chunking");
+    const float* __restrict__ resid = p.resid;
+    float* __restrict__ out = (float*)p.out;
+    int ncol[NF];
+    f32x4 bias[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = nb + j * 16 + fq * 4;
+        ncol[j] = n;
+        const int nc = min(n, p.N - 4);
+        bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < MI; c += MI_CH) {
+        f32x4 rs[MI_CH][NF];
+#pragma unroll
+        for (int ii = 0; ii < MI_CH; ++ii) {
+            const size_t ro = (size_t)min(mrow0 + (c + ii) * 16, p.M - 1) * p.ldo;
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                rs[ii][j] = *reinterpret_cast<const f32x4*>(resid + ro + min(ncol[j], p.N - 4));
+        }
+#pragma unroll
+        for (int ii = 0; ii < MI_CH; ++ii) {
+            const int m = mrow0 + (c + ii) * 16;
+            if (m < p.M) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    if (ncol[j] < p.N)
+                        *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + ncol[j]) =
+                            rs[ii][j] + p.alpha * (acc[c + ii][j] + bias[j]);
+            }
+        }
+    }
+}
+
+}  // namespace vr
