@@ -173,11 +173,11 @@ def main():
     dom = max(gemm_like, key=lambda k: gemm_like[k]["ms"])
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    kernel_names = {"vit_qkv": "gemm_bf16_kernel<EPI_BF16,GLDS> (ViT qkv)",
-                    "vit_attn": "attention_kernel<72,2> (ViT self-attention)",
-                    "vit_proj": "gemm_bf16_kernel<EPI_RESID,GLDS> (ViT attn proj)",
-                    "vit_fc1": "gemm_bf16_kernel<EPI_GELU,GLDS> (ViT MLP fc1)",
-                    "vit_fc2": "gemm_bf16_kernel<EPI_RESID,GLDS> (ViT MLP fc2)"}
+    kernel_names = {"vit_qkv": "vr::gemm256_bf16_kernel<0, 0> (EPI_BF16; ViT qkv, 256x256 tile)",
+                    "vit_attn": "vr::attention_kernel<72, 2> (ViT self-attention)",
+                    "vit_proj": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT attn proj, 256x192 tile)",
+                    "vit_fc1": "vr::gemm256_bf16_kernel<1, 0> (EPI_GELU; ViT MLP fc1, 256x256 tile)",
+                    "vit_fc2": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT MLP fc2, 256x192 tile)"}
     roofline = {"bound": "mfma", "kernel": kernel_names[dom], "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
@@ -214,6 +214,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import visrag_ret_oracle as O
+            # 16 threads is the fastest setting for this fp32 forward on the many-core host
+            # (measured: 16 -> 2.4 s/page, 32 -> 2.6, 64 -> 4.4, 128 -> 11 s/page)
+            torch.set_num_threads(min(16, os.cpu_count() or 16))
             tc = time.time()
             W = {k: v.cpu() for k, v in iter_synth_weights(cfg, 0, device=dev)}
             log(f"cpu weights in {time.time() - tc:.1f}s; threads={torch.get_num_threads()}")
