@@ -1,0 +1,81 @@
+"""-m gpu: the reference's encode -> pickle shards -> retrieve -> TREC pipeline driven through the
+drop-in entry points (inference.distributed_parallel_embedding_inference,
+retriever.distributed_parallel_retrieve, utils.save_as_trec) on the tiny-dims model, against the
+oracle's embeddings + retrieval on the same inputs (config 1 of BASELINE.json in miniature:
+pages + text queries, brute-force cosine top-3)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import visrag_ret_oracle as O  # noqa: E402
+from visrag_amd import utils as U  # noqa: E402
+from visrag_amd.config import tiny_config  # noqa: E402
+from visrag_amd.engine import HipEncoder  # noqa: E402
+from visrag_amd.inference import distributed_parallel_embedding_inference  # noqa: E402
+from visrag_amd.modeling import DRModelForInference, encode  # noqa: E402
+from visrag_amd.preprocess import prepare_batch  # noqa: E402
+from visrag_amd.retriever import distributed_parallel_retrieve  # noqa: E402
+from visrag_amd.synth import iter_synth_weights, synth_pages, synth_queries, synth_state_dict  # noqa: E402
+from visrag_amd.tokenizer import StandInTokenizer  # noqa: E402
+
+QUERY_PREFIX = "Represent this query for retrieving relevant documents: "
+
+
+def test_encode_retrieve_trec_pipeline(tmp_path):
+    from PIL import Image
+    cfg = tiny_config()
+    enc = HipEncoder(cfg, max_images=8, max_tokens=1024, max_seqs=8)
+    enc.load_state_dict(iter_synth_weights(cfg, 0, device="cuda"))
+    model = DRModelForInference(cfg, enc)
+    tok = StandInTokenizer(cfg.vocab_size)
+    n_pages, n_q, k = 24, 6, 3
+    pages = synth_pages(n_pages, size=cfg.scale_resolution, seed=3)
+    qtexts = [QUERY_PREFIX + q for q in synth_queries(n_q, seed=3)]
+    corpus = [{"id": f"d{i}", "text": "", "image": Image.fromarray(p)} for i, p in enumerate(pages)]
+    queries = [{"id": f"q{i}", "text": t, "image": None} for i, t in enumerate(qtexts)]
+    args = types.SimpleNamespace(output_dir=str(tmp_path), per_device_eval_batch_size=5, process_index=0,
+                                 world_size=1, max_inmem_docs=10, device="cuda:0")
+    extra = {"tokenizer": tok, "max_inp_length": 2048}
+    distributed_parallel_embedding_inference(corpus, model, args, "corpus", True, extra)
+    distributed_parallel_embedding_inference(queries, model, args, "query", False, extra)
+    names = sorted(os.listdir(tmp_path))
+    assert "embeddings.query.rank.0" in names and sum(n.startswith("embeddings.corpus.rank.0.") for n in names) >= 2
+    reps, ids = U.read_shard(os.path.join(tmp_path, [n for n in names if n.startswith("embeddings.corpus")][0]))
+    assert reps.dtype == np.float32 and reps.shape[1] == cfg.hidden_size and len(ids) == len(reps)
+
+    run = distributed_parallel_retrieve(args, k)
+    union = distributed_parallel_retrieve(args, k, per_shard=True)      # reference semantics: k per shard
+    assert all(len(v) == k for v in run.values()) and all(len(v) >= k for v in union.values())
+    U.save_as_trec(run, os.path.join(tmp_path, "trec", "test.0.trec"))
+    assert U.load_from_trec(os.path.join(tmp_path, "trec", "test.0.trec")).keys() == run.keys()
+
+    # ---- oracle on the same inputs
+    W = synth_state_dict(cfg, 0)
+    pit = prepare_batch([""] * n_pages, [c["image"] for c in corpus], tok, cfg, 2048)
+    qit = prepare_batch(qtexts, [None] * n_q, tok, cfg, 2048)
+    P = O.encode(W, cfg, [i.input_ids for i in pit], [i.image_bound for i in pit], [i.slices for i in pit]).numpy()
+    Q = O.encode(W, cfg, [i.input_ids for i in qit], [[]] * n_q, [[]] * n_q).numpy()
+    ref = O.retrieve(Q, [f"q{i}" for i in range(n_q)], [(P, [f"d{i}" for i in range(n_pages)])], n_pages)
+    tol = 2.5e-3                       # 256-d tiny model (1e-3 is asserted at full dims)
+    for q, docs in run.items():
+        ranked = sorted(ref[q].items(), key=lambda kv: -kv[1])
+        for d, s in docs.items():                                   # scores agree with the oracle
+            assert abs(ref[q][d] - s) < tol, (q, d, ref[q][d], s)
+        gap = ranked[k - 1][1] - ranked[k][1]
+        if gap > 2 * tol:                                            # top-k set identical when well separated
+            assert set(docs) == {d for d, _ in ranked[:k]}, (q, docs, ranked[:k + 1])
+        for d in docs:                                               # always: nothing outside the tolerance band
+            assert ref[q][d] >= ranked[k - 1][1] - 2 * tol
+    # the union result contains the global top-k
+    for q in run:
+        assert set(run[q]) <= set(union[q])
+    # demo helper signature (visrag_scripts/demo/visrag_pipeline/utils.py:12-32)
+    e = encode(model, tok, [c["image"] for c in corpus[:2]])
+    assert e.shape == (2, cfg.hidden_size) and np.allclose(np.linalg.norm(e, axis=1), 1, atol=1e-5)
+    e = encode(model, tok, ["a text query"])
+    assert e.shape == (1, cfg.hidden_size)
