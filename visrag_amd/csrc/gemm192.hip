@@ -65,26 +65,39 @@ __global__ __launch_bounds__(512, 2) void gemm192_bf16_kernel(GemmArgs p) {
         }
         const char* tA = cur;
         const char* tW = cur + G192_A_BYTES;
+        // fragment reads interleaved with the MFMAs (see gemm_core_il.h): strip i+1's A fragment —
+        // or, in the last strip, the seven fragments that open the next K-half — is requested before
+        // strip i's six MFMAs are issued
+        auto frag = [&](const char* t, int row, int kk) {
+            return *reinterpret_cast<const bf16x8*>(t + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
+        };
+        const int arow = wm * 64 + fr, wrow = wn * 96 + fr;
+        bf16x8 w[6], wnx[6], a0, b0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) w[j] = frag(tW, wrow + j * 16, 0);
+        a0 = frag(tA, arow, 0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], w[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int row = wn * 96 + j * 16 + fr;
-                w[j] = *reinterpret_cast<const bf16x8*>(tW + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + fr;
-                a[i] = *reinterpret_cast<const bf16x8*>(tA + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
-            }
-            __builtin_amdgcn_s_setprio(1);
+                if (i < 3) {
+                    b0 = frag(tA, arow + (i + 1) * 16, kk);
+                } else if (kk == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 6; ++j) wnx[j] = frag(tW, wrow + j * 16, 1);
+                    b0 = frag(tA, arow, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a0, acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = b0;
+                if (i == 3 && kk == 0) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) w[j] = wnx[j];
+                }
+            }
         }
     }
     if constexpr (EPI == EPI_RESID) {

@@ -9,7 +9,7 @@ namespace vr {
 enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_SWIGLU = 4, EPI_ROPE = 5 };
 // GLDS/REG: 128x128 tile (LDS-DMA / register staging); 256: 256x256 8-wave tile (needs W and A
 // readable up to the next multiple of 256 rows); AUTO picks by M.
-enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1, GEMM_VARIANT_256 = 2, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_256P4 = 4, GEMM_VARIANT_256MID = 5, GEMM_VARIANT_256STAG = 6, GEMM_VARIANT_192 = 7, GEMM_VARIANT_32 = 8 };
+enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1, GEMM_VARIANT_256 = 2, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_256P4 = 4, GEMM_VARIANT_256MID = 5, GEMM_VARIANT_256STAG = 6, GEMM_VARIANT_192 = 7, GEMM_VARIANT_32 = 8, GEMM_VARIANT_256IL = 9 };
 
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M_pad][lda]
