@@ -150,3 +150,26 @@ def test_full_dims_vs_reference_golden(golden_dir):
     assert ((q * g["q_reps"]).sum(1)).min() > 1 - TOL
     np.testing.assert_allclose(q @ p.T, g["q_reps"] @ g["p_reps"].T, atol=TOL)
     enc.close()
+
+
+def test_full_dims_sliced_page_vs_oracle():
+    """A real-document-sized page (1114x1670 -> source 364x546 + 2x4 slices of 518x392, 9 ViT
+    images on non-square 26x39 / 28x37 grids, 576 image tokens) at full dims against the CPU
+    oracle run here: exercises the per-grid pos-embed resample, ragged attention and the
+    multi-bound scatter."""
+    cfg = full_config()
+    enc = HipEncoder(cfg, max_images=12, max_tokens=2048, max_seqs=4)
+    sd_gpu = dict(iter_synth_weights(cfg, 0, device="cuda"))
+    enc.load_state_dict(sd_gpu.items())
+    W = {k: v.cpu() for k, v in sd_gpu.items()}
+    del sd_gpu
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    tok = StandInTokenizer(cfg.vocab_size)
+    big = np.ascontiguousarray(np.tile(synth_pages(1, size=448, seed=9)[0], (4, 3, 1))[:1670, :1114])
+    items = prepare_batch(["chart of revenue"], [_pil(big)], tok, cfg, 2048)
+    assert len(items[0].slices) == 9 and len(items[0].image_bound) == 9
+    assert {s.shape[:2] for s in items[0].slices} == {(546, 364), (392, 518)}
+    got = DRModelForInference(cfg, enc).encode_prepared(items).cpu().numpy()
+    ref = O.encode(W, cfg, [items[0].input_ids], [items[0].image_bound], [items[0].slices]).numpy()
+    assert float((got * ref).sum()) > 1 - TOL
+    enc.close()
