@@ -128,6 +128,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_32) return launch_gemm32(a, epi, s);
+    if (variant == GEMM_VARIANT_256P) return launch_gemm256p(a, epi, s);
+    if (variant >= 20 && variant <= 26) return launch_gemm_ablate(a, variant, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel
         if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID)
@@ -142,7 +144,10 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         const long t128 = (long)(a.N / 128) * ((a.M + 127) / 128);
         const double e256 = 1.25 * (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        variant = (n_ok && e256 > e128) ? GEMM_VARIANT_256IL : GEMM_VARIANT_GLDS;   // IL: +2..5 % on K=1152
+        // interleaved 256 kernel.  The persistent one (variant 10) is +5 % in an isolated loop but
+        // -15 % inside the model (A/B in one session: qkv 8.66 vs 7.33 ms/step) — it stays an experiment.
+        static const int env256 = getenv("VR_GEMM256") ? atoi(getenv("VR_GEMM256")) : 0;   // A/B aid
+        variant = (n_ok && e256 > e128) ? (env256 ? env256 : GEMM_VARIANT_256IL) : GEMM_VARIANT_GLDS;
     }
     switch (epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(a, variant, s);

@@ -1,0 +1,108 @@
+// Timing ablations of the 256x256 GEMM main loop (results are NOT valid products): which of
+// {LDS-DMA, fragment reads, barrier, MFMA} bounds the loop.  Reached through vr_op_gemm variants
+// 20..23; never used by the engine.
+//   20: no LDS-DMA after the first tile (reads + MFMA + barrier)
+//   21: no fragment reads after the first (LDS-DMA + MFMA + barrier)
+//   22: MFMA only (fragments loaded once, no barrier, no DMA)
+//   23: LDS-DMA + barrier only (no reads, no MFMA)
+#include "gemm_core.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace vr {
+
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_ablate_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (p.N + 255) / 256;
+    const int t = xcd_remap(blockIdx.x, tiles_n * ((p.M + 255) / 256));
+    const int m0 = (t / tiles_n) * 256, n0 = (t % tiles_n) * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* W = (const bf16_t*)p.W;
+    gemm256_acc_t acc;
+    gemm256_zero(acc);
+    const int nk = p.K / GEMM_BK;
+    stage_glds(A, p.lda, m0, 0, smem, wave, lane);
+    stage_glds(W, p.ldw, n0, 0, smem + G256_TILE_BYTES, wave, lane);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    bf16x8 a[8], w[4];
+    auto rd = [&](const char* tA, const char* tW, int kk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wn * 64 + j * 16 + fr;
+            w[j] = *reinterpret_cast<const bf16x8*>(tW + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = wm * 128 + i * 16 + fr;
+            a[i] = *reinterpret_cast<const bf16x8*>(tA + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
+        }
+    };
+    rd(smem, smem + G256_TILE_BYTES, 0);
+    if (ABL == 26) {   // plain global_load_dwordx4 to registers (no LDS write), one tile in flight
+        for (int kt = 0; kt < nk; ++kt) {
+            u32x4 ra[4], rw[4], rb[4], rc[4];
+            stage_load(A, p.lda, m0, kt * GEMM_BK, tid & 255, ra);
+            stage_load(A, p.lda, m0 + 128, kt * GEMM_BK, tid & 255, rb);
+            stage_load(W, p.ldw, n0, kt * GEMM_BK, tid & 255, rw);
+            stage_load(W, p.ldw, n0 + 128, kt * GEMM_BK, tid & 255, rc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(ra[i]), "v"(rb[i]), "v"(rw[i]), "v"(rc[i]));
+            __syncthreads();
+        }
+    } else if (ABL == 24 || ABL == 25) {   // LDS-DMA only, DEPTH tiles in flight (counted vmcnt, raw barrier)
+        constexpr int DEPTH = ABL == 24 ? 2 : 3;
+        for (int d = 1; d < DEPTH; ++d) {
+            stage_glds(A, p.lda, m0, d * GEMM_BK, smem + (d & 1) * 2 * G256_TILE_BYTES, wave, lane);
+            stage_glds(W, p.ldw, n0, d * GEMM_BK, smem + (d & 1) * 2 * G256_TILE_BYTES + G256_TILE_BYTES, wave, lane);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (DEPTH == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            const int nx = min(kt + DEPTH, nk - 1);
+            char* dst = smem + (nx & 1) * 2 * G256_TILE_BYTES;
+            stage_glds(A, p.lda, m0, nx * GEMM_BK, dst, wave, lane);
+            stage_glds(W, p.ldw, n0, nx * GEMM_BK, dst + G256_TILE_BYTES, wave, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    } else
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * 2 * G256_TILE_BYTES;
+        char* nxt = smem + ((kt + 1) & 1) * 2 * G256_TILE_BYTES;
+        if (ABL != 22) __syncthreads();
+        if ((ABL == 21 || ABL == 23) && kt + 1 < nk) {
+            stage_glds(A, p.lda, m0, (kt + 1) * GEMM_BK, nxt, wave, lane);
+            stage_glds(W, p.ldw, n0, (kt + 1) * GEMM_BK, nxt + G256_TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (ABL == 20) rd(cur, cur + G256_TILE_BYTES, kk);
+            if (ABL != 23) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        gemm_epilogue_row<EPI_BF16>(acc[i], p, m0 + wm * 128 + i * 16 + fr, n0 + wn * 64, fq);
+}
+
+hipError_t launch_gemm_ablate(const GemmArgs& a, int abl, hipStream_t s) {
+    const int tiles = ((a.N + 255) / 256) * ((a.M + 255) / 256);
+    void (*k)(GemmArgs) = abl == 20 ? gemm_ablate_kernel<20> : abl == 21 ? gemm_ablate_kernel<21>
+                        : abl == 22 ? gemm_ablate_kernel<22> : abl == 23 ? gemm_ablate_kernel<23>
+                        : abl == 24 ? gemm_ablate_kernel<24> : abl == 25 ? gemm_ablate_kernel<25>
+                        : gemm_ablate_kernel<26>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), G256_SMEM_BYTES, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace vr
