@@ -157,6 +157,13 @@ int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k,
 int vr_topk_merge(int device_id, const float* scores, const int64_t* ids, int32_t n_parts,
                   int32_t nq, int32_t k, float* out_scores, int64_t* out_ids, void* stream);
 
+/* ---- host pre-processing moved to the GPU ------------------- */
+/* Bicubic resize of an 8-bit RGB (HWC) image, bit-exact with Pillow's
+ * Image.resize((out_w, out_h), Image.Resampling.BICUBIC) — the resize of slice_image /
+ * find_best_resize (modeling_minicpmv.py:482-537).  src on host or device, dst on device. */
+int vr_resize_bicubic(int device_id, const uint8_t* src, int32_t src_on_device, int32_t H, int32_t W,
+                      uint8_t* dst, int32_t out_h, int32_t out_w, void* stream);
+
 /* ---- single kernels (parity tests and micro-benchmarks call these through the ABI) ---- */
 /* out[M][N] = epilogue(A[M][K] * W[N][K]^T).  A, W bf16 row-major, K % 64 == 0,
  * N % 128 == 0, buffers padded to a multiple of 128 rows.  epilogue:

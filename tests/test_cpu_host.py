@@ -138,3 +138,15 @@ def test_sharded_retrieval_world2_gloo(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_pil_resize_oracle_is_bit_exact():
+    """oracle/pil_resize_oracle.py (the arithmetic resize.hip implements) == Pillow, bit for bit."""
+    from PIL import Image
+    from oracle.pil_resize_oracle import resize_bicubic
+    rng = np.random.default_rng(0)
+    for (h, w), (ow, oh) in [((300, 200), (140, 84)), ((200, 300), (364, 546)), ((64, 50), (518, 392)),
+                             ((333, 517), (112, 112)), ((100, 100), (100, 37)), ((97, 131), (210, 131))]:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.Resampling.BICUBIC))
+        assert np.array_equal(resize_bicubic(img, (ow, oh)), ref), ((h, w), (ow, oh))

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vr_index_size": (C.c_int, [_vp, C.POINTER(_i64)]),
     "vr_index_search": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "vr_topk_merge": (C.c_int, [C.c_int, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vr_resize_bicubic": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "vr_op_gemm": (C.c_int, [C.c_int, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32,
                              _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "vr_op_norm": (C.c_int, [C.c_int, _i32, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp]),

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -1086,6 +1087,65 @@ extern "C" int vr_topk_merge(int device_id, const float* scores, const int64_t* 
     VRCHK(set_dev(device_id));
     HIPCHK(launch_topk_merge(scores, ids, n_parts, nq, k, out_scores, out_ids, (hipStream_t)stream));
     return VR_OK;
+}
+
+// -------------------------------------------------------------------------------- resize ---
+// coefficient tables are cached per (device, in, out): a corpus has a handful of page sizes
+struct ResizeTab { DevBuf bounds, kk; int ksize = 0; };
+static std::map<std::tuple<int, int, int>, ResizeTab> g_resize_tabs;
+
+static int get_resize_tab(int dev, int in_size, int out_size, ResizeTab** out) {
+    auto key = std::make_tuple(dev, in_size, out_size);
+    auto it = g_resize_tabs.find(key);
+    if (it == g_resize_tabs.end()) {
+        std::vector<int> b, k;
+        ResizeTab t;
+        t.ksize = resize_coeffs(in_size, out_size, b, k);
+        VRCHK(t.bounds.alloc(b.size() * 4));
+        VRCHK(t.kk.alloc(k.size() * 4));
+        HIPCHK(hipMemcpy(t.bounds.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t.kk.p, k.data(), k.size() * 4, hipMemcpyHostToDevice));
+        it = g_resize_tabs.emplace(key, std::move(t)).first;
+    }
+    *out = &it->second;
+    return VR_OK;
+}
+
+extern "C" int vr_resize_bicubic(int device_id, const uint8_t* src, int32_t src_on_device, int32_t H, int32_t W,
+                                 uint8_t* dst, int32_t out_h, int32_t out_w, void* stream) {
+    if (!src || !dst || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return fail(VR_ERR_INVALID, "bad resize arguments");
+    VRCHK(set_dev(device_id));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf in_dev, tmp;
+    const uint8_t* in = src;
+    if (!src_on_device) {
+        VRCHK(in_dev.alloc((size_t)H * W * 3));
+        HIPCHK(hipMemcpyAsync(in_dev.p, src, (size_t)H * W * 3, hipMemcpyHostToDevice, s));
+        in = in_dev.as<uint8_t>();
+    }
+    const bool need_h = out_w != W, need_v = out_h != H;
+    int rc = VR_OK;
+    if (!need_h && !need_v) {
+        HIPCHK(hipMemcpyAsync(dst, in, (size_t)H * W * 3, hipMemcpyDeviceToDevice, s));
+    } else {
+        const uint8_t* mid = in;
+        if (need_h) {
+            ResizeTab* th = nullptr;
+            VRCHK(get_resize_tab(device_id, W, out_w, &th));
+            uint8_t* hout = dst;
+            if (need_v) { VRCHK(tmp.alloc((size_t)H * out_w * 3)); hout = tmp.as<uint8_t>(); }
+            HIPCHK(launch_resize_h(in, W, H, hout, out_w, th->bounds.as<int>(), th->kk.as<int>(), th->ksize, s));
+            mid = hout;
+        }
+        if (need_v) {
+            ResizeTab* tv = nullptr;
+            VRCHK(get_resize_tab(device_id, H, out_h, &tv));
+            HIPCHK(launch_resize_v(mid, out_w, dst, out_h, tv->bounds.as<int>(), tv->kk.as<int>(), tv->ksize, s));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));     // temporaries are freed on return
+    in_dev.free(); tmp.free();
+    return rc;
 }
 
 // ------------------------------------------------------------------------------ op-level ---

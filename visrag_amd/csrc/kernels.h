@@ -73,6 +73,16 @@ hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t 
 hipError_t launch_split_bf16(const float* in, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t launch_iota_pos(const int* seq_offsets, int B, int* pos, hipStream_t s);
 
+// ---- PIL-exact bicubic resize (resize.hip) ------------------------------------------------------
+} // namespace vr
+#include <vector>
+namespace vr {
+int resize_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk);   // returns ksize
+hipError_t launch_resize_h(const uint8_t* in, int in_w, int rows, uint8_t* out, int out_w, const int* bounds,
+                           const int* kk, int ksize, hipStream_t s);
+hipError_t launch_resize_v(const uint8_t* in, int w, uint8_t* out, int out_h, const int* bounds, const int* kk,
+                           int ksize, hipStream_t s);
+
 // ---- search (search.hip) -------------------------------------------------------------------
 struct SearchArgs {
     const void* index_bf16;          // [n_docs_pad][dim] bf16

@@ -96,8 +96,12 @@ class HipEncoder:
         slices: List = []
         hw: List[int] = []
         rows: List[np.ndarray] = []
+        di = 0
         for i, it in enumerate(items):
             for k, s in enumerate(it.slices):
+                if device_slices is not None:     # shapes come from the device tensors (host slice may be None)
+                    s = device_slices[di]
+                di += 1
                 slices.append(s)
                 hw += [int(s.shape[0]), int(s.shape[1])]
                 r = np.full(Q, -1, dtype=np.int32)

@@ -1,0 +1,74 @@
+"""GPU side of the MiniCPM-V slicing policy: Pillow-exact bicubic resize + slice cropping on the
+device.  Same policy as preprocess.slice_image
+(modeling_minicpmv.py:482-537); the resized pixels are bit-identical to PIL's, so embeddings do
+not depend on which side resized."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .preprocess import (PreparedItem, choose_grid, find_best_resize, get_grid_placeholder, get_refine_size,
+                         image_placeholder)
+
+
+def resize_bicubic(img, size: Tuple[int, int], device: int = 0) -> torch.Tensor:
+    """img: uint8 HWC numpy array or cuda tensor; size = (out_w, out_h) like PIL.  -> cuda uint8 [oh, ow, 3]."""
+    lib = _lib.load()
+    ow, oh = int(size[0]), int(size[1])
+    out = torch.empty((oh, ow, 3), dtype=torch.uint8, device=f"cuda:{device}")
+    if isinstance(img, torch.Tensor):
+        assert img.is_cuda and img.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 3
+        img = img.contiguous()
+        H, W = int(img.shape[0]), int(img.shape[1])
+        src, on_dev = C.c_void_p(img.data_ptr()), 1
+    else:
+        a = np.ascontiguousarray(img, dtype=np.uint8)
+        assert a.ndim == 3 and a.shape[2] == 3
+        H, W = a.shape[:2]
+        src, on_dev = C.c_void_p(a.ctypes.data), 0
+    _lib.check(lib.vr_resize_bicubic(device, src, on_dev, H, W, C.c_void_p(out.data_ptr()), oh, ow,
+                                     C.c_void_p(int(torch.cuda.current_stream().cuda_stream))), "vr_resize_bicubic")
+    return out
+
+
+def slice_image_gpu(img, cfg, device: int = 0):
+    """-> (list of cuda uint8 HWC slices [source, patches row-major...], best_grid|None)."""
+    if isinstance(img, torch.Tensor):
+        H, W = int(img.shape[0]), int(img.shape[1])
+    else:
+        img = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img, dtype=np.uint8)
+        H, W = img.shape[:2]
+    size = (W, H)
+    grid = choose_grid(size, cfg.max_slice_nums, cfg.scale_resolution)
+    if grid is None:
+        best = find_best_resize(size, cfg.scale_resolution, cfg.patch_size, allow_upscale=True)
+        return [resize_bicubic(img, best, device)], None
+    src = resize_bicubic(img, find_best_resize(size, cfg.scale_resolution, cfg.patch_size), device)
+    refine = get_refine_size(size, grid, cfg.scale_resolution, cfg.patch_size, allow_upscale=True)
+    refined = resize_bicubic(img, refine, device)
+    cw, ch = int(refine[0] / grid[0]), int(refine[1] / grid[1])
+    out = [src]
+    for y in range(0, refine[1], ch):
+        for x in range(0, refine[0], cw):
+            out.append(refined[y:y + ch, x:x + cw].contiguous())      # strided device copy (plumbing)
+    return out, grid
+
+
+def prepare_item_gpu(text: str, image, tokenizer, cfg, max_inp_length: Optional[int] = 2048, device: int = 0):
+    """GPU-preprocessing twin of preprocess.prepare_item: returns (PreparedItem with placeholder
+    slices, list of device slices)."""
+    from .preprocess import prepare_item
+    dev_slices: List[torch.Tensor] = []
+    if image is None:
+        return prepare_item(text, None, tokenizer, cfg, max_inp_length), dev_slices
+    dev_slices, grid = slice_image_gpu(image, cfg, device)
+    ph = image_placeholder(tokenizer, cfg.query_num)
+    if grid is not None:
+        ph += get_grid_placeholder(tokenizer, grid, cfg.query_num)
+    it = prepare_item(ph + "\n" + text, None, tokenizer, cfg, max_inp_length)
+    it.slices = [None] * len(dev_slices)
+    return it, dev_slices
