@@ -22,7 +22,8 @@ def _unit(n, d, seed):
 
 
 @pytest.mark.parametrize("nd,nq,dim,k", [(5000, 37, 256, 10), (130, 3, 64, 5), (20000, 300, 2304, 10),
-                                          (1000, 130, 128, 20), (7, 2, 64, 10)])
+                                          (1000, 130, 128, 20), (7, 2, 64, 10),
+                                          (3001, 257, 128, 26), (40037, 1000, 512, 10), (255, 129, 64, 3)])
 def test_search_matches_oracle(nd, nq, dim, k):
     C, Q = _unit(nd, dim, 1), _unit(nq, dim, 2)
     ix = HipIndex(dim, nd)
@@ -31,8 +32,11 @@ def test_search_matches_oracle(nd, nq, dim, k):
     sc, ids = ix.search(Q, k)
     rs, ri = O.search_topk(Q, C, k)
     kk = min(k, nd)
-    assert np.array_equal(ids[:, :kk], ri)
     np.testing.assert_allclose(sc[:, :kk], rs, atol=1e-5, rtol=0)
+    # ids identical, except where two fp32 scores are within summation-order rounding of each other
+    for q, c in np.argwhere(ids[:, :kk] != ri):
+        j = int(np.flatnonzero(ri[q] == ids[q, c])[0]) if ids[q, c] in ri[q] else -1
+        assert j >= 0 and abs(rs[q, j] - rs[q, c]) < 3e-7, (q, c, ids[q, c], ri[q, c])
     if kk < k:
         assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()
 

@@ -969,8 +969,8 @@ struct vr_index_s {
     int device = 0, dim = 0;
     int64_t cap = 0, n = 0;
     DevBuf f32, bf16;                 // [cap_pad][dim]
-    DevBuf q32, qbf, cs, ci, os, oi, thr;  // query staging / candidates / outputs / thresholds
-    int64_t qcap = 0, ccap = 0;
+    DevBuf q32, qbf, cs, ci, ck, os, oi, thr;  // query staging / candidates / outputs / thresholds
+    int64_t qcap = 0, ccap = 0, kcap = 0;
 };
 
 extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_index_t* out) {
@@ -980,7 +980,7 @@ extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_
     VRCHK(set_dev(device_id));
     vr_index_s* ix = new vr_index_s();
     ix->device = device_id; ix->dim = dim; ix->cap = capacity;
-    const int64_t cp = pad128l(capacity);
+    const int64_t cp = pad256l(capacity);
     int r = ix->f32.alloc((size_t)cp * dim * 4);
     if (r == VR_OK) r = ix->bf16.alloc((size_t)cp * dim * 2);
     if (r != VR_OK) { ix->f32.free(); ix->bf16.free(); delete ix; return r; }
@@ -992,7 +992,7 @@ extern "C" int vr_index_destroy(vr_index_t ix) {
     if (!ix) return VR_OK;
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->os, &ix->oi, &ix->thr}) b->free();
+    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->ck, &ix->os, &ix->oi, &ix->thr}) b->free();
     delete ix;
     return VR_OK;
 }
@@ -1031,7 +1031,7 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
     VRCHK(set_dev(ix->device));
     hipStream_t s = (hipStream_t)stream;
     const int dim = ix->dim;
-    const int64_t nqp = pad128l(nq);
+    const int64_t nqp = pad256l(nq);
     if (ix->qcap < nqp) {
         VRCHK(ix->q32.alloc((size_t)nqp * dim * 4));
         VRCHK(ix->qbf.alloc((size_t)nqp * dim * 2));
@@ -1070,6 +1070,11 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
             ix->ccap = need;
         }
         a.cand_scores = ix->cs.as<float>(); a.cand_ids = ix->ci.as<int>();
+        if (search_uses_256(nq)) {
+            const int64_t kneed = nqp * a.n_chunks * 64;
+            if (ix->kcap < kneed) { VRCHK(ix->ck.alloc((size_t)kneed * 8)); ix->kcap = kneed; }
+            a.cand_keys = ix->ck.as<unsigned long long>();
+        }
         a.out_scores = os; a.out_ids = oi;
         HIPCHK(launch_search(a, s));
     }

@@ -95,10 +95,13 @@ struct SearchArgs {
     float* cand_scores; int* cand_ids; int n_chunks;   // workspace [nq_pad][n_chunks][KP]
     float* out_scores; int64_t* out_ids;               // [nq][k]
     float* thr_init;                                   // workspace [nq_pad] or null (no pre-pass)
+    unsigned long long* cand_keys;                     // 256-tile sweep scratch [nq_pad256][n_chunks][64] or null
 };
 int search_kprime(int k);            // candidates kept per (query, chunk); 0 if k unsupported
 int search_num_chunks(int64_t n_docs, int nq);
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
+bool search_uses_256(int nq);         // more than 128 queries: main sweep on the 256^2 tile (search256.hip)
+hipError_t launch_sweep256(const SearchArgs& a, int kp, const float* thr, hipStream_t s);
 hipError_t launch_topk_merge(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t s);
 

@@ -16,62 +16,13 @@
 // Block placement: the 8 query tiles of a chunk are consecutive on ONE XCD (b % 8 == chunk % 8)
 // so the index tile is fetched from HBM once and re-read from that XCD's L2.
 // Roofline: MFMA for Nq >~ 300 (2*Nq*Nd*D flop), HBM for small Nq (Nd*D*2 bytes per sweep).
+#include <cstdlib>
+
 #include "gemm_core.h"
+#include "search_common.h"
 #include "kernels.h"
 
 namespace vr {
-
-constexpr int SRCH_CAP = 64;        // per-query LDS candidate buffer (one entry per lane)
-constexpr int SRCH_TRIG = 32;       // compact when a buffer holds more than this
-
-__device__ __forceinline__ uint32_t f32_orderable(float f) {
-    const uint32_t u = __float_as_uint(f);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float orderable_f32(uint32_t o) {
-    const uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-    return __uint_as_float(u);
-}
-// sort key: larger key = better candidate (higher score, then LOWER id)
-__device__ __forceinline__ uint64_t make_key(float score, uint32_t id) {
-    return ((uint64_t)f32_orderable(score) << 32) | (uint32_t)(~id);
-}
-constexpr uint64_t KEY_NONE = 0;    // below every real key (score -inf, id 0xffffffff -> ~ = 0 ...)
-
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
-    const uint32_t lo = __shfl((uint32_t)v, src, 64);
-    const uint32_t hi = __shfl((uint32_t)(v >> 32), src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// 64-lane bitonic sort, descending: lane 0 ends with the largest key.
-__device__ __forceinline__ uint64_t wave_bitonic_desc(uint64_t key, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint64_t other = shfl_xor_u64(key, j);
-            const bool desc = (lane & k) == 0;
-            const bool low = (lane & j) == 0;
-            const bool keep_max = (desc == low);
-            const uint64_t mx = key > other ? key : other, mn = key > other ? other : key;
-            key = keep_max ? mx : mn;
-        }
-    }
-    return key;
-}
-// top-64 of (sorted-desc `cur`) U (arbitrary `fresh`), sorted descending
-__device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fresh, int lane) {
-    fresh = wave_bitonic_desc(fresh, lane);
-    const uint64_t rev = shfl_u64(fresh, 63 - lane);
-    const uint64_t best = cur > rev ? cur : rev;      // bitonic sequence holding the top 64
-    return wave_bitonic_desc(best, lane);
-}
 
 struct SweepLds {
     float thr[128];
@@ -260,7 +211,21 @@ int search_kprime(int k) {
     return 0;
 }
 
+bool search_uses_256(int nq) {
+    static int force = -1;           // tuning aid: VR_SEARCH_TILE=128 keeps every search on the 128^2 sweep
+    if (force < 0) { const char* e = getenv("VR_SEARCH_TILE"); force = (e && atoi(e) == 128) ? 1 : 0; }
+    return nq > 128 && !force;
+}
+
 int search_num_chunks(int64_t n_docs, int nq) {
+    if (search_uses_256(nq)) {       // one 8-wave workgroup per CU: ~256 workgroups
+        const int q_tiles = (nq + 255) / 256;
+        const int n_tiles = (int)((n_docs + 255) / 256);
+        int chunks = ((256 / q_tiles) + 7) / 8 * 8;
+        if (chunks < 8) chunks = 8;
+        while (chunks > 8 && chunks > n_tiles) chunks -= 8;
+        return chunks;
+    }
     const int q_tiles = (nq + 127) / 128;
     const int n_tiles = (int)((n_docs + 127) / 128);
     int chunks = ((512 / q_tiles) + 7) / 8 * 8;          // ~2 workgroups per CU
@@ -292,9 +257,13 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         if ((e = hipGetLastError()) != hipSuccess) return e;
         thr = a.thr_init;
     }
-    const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
-    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc, 1, thr);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (search_uses_256(a.nq)) {
+        if ((e = launch_sweep256(a, KP, thr, s)) != hipSuccess) return e;
+    } else {
+        const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
+        hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc, 1, thr);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(search_merge_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
