@@ -6,7 +6,8 @@ nd, dim = 100_000, 2304
 g = torch.Generator(device="cuda").manual_seed(0)
 C = torch.randn((nd, dim), generator=g, device="cuda"); C = C / C.norm(dim=1, keepdim=True)
 ix = HipIndex(dim, nd); ix.add(C)
-for nq in (1000, 128, 16, 1):
+nqs = [int(x) for x in sys.argv[1:]] or [1000, 128, 16, 1]
+for nq in nqs:
     Q = torch.randn((nq, dim), generator=g, device="cuda"); Q = Q / Q.norm(dim=1, keepdim=True)
     for _ in range(3): ix.search(Q, 10)
     torch.cuda.synchronize()

@@ -1063,7 +1063,7 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
         a.q_bf16 = ix->qbf.p; a.q_f32 = q32; a.nq = nq; a.k = k;
         a.n_chunks = search_num_chunks(ix->n, nq);
         a.thr_init = ix->thr.as<float>();
-        const int64_t need = nqp * std::max(a.n_chunks, 8) * kp;
+        const int64_t need = std::max<int64_t>(nqp * a.n_chunks * kp, nqp * search_prepass_floats());
         if (ix->ccap < need) {
             VRCHK(ix->cs.alloc((size_t)need * 4));
             VRCHK(ix->ci.alloc((size_t)need * 4));

@@ -77,4 +77,42 @@ __device__ __forceinline__ void gemm256_mainloop_il(gemm256_acc_t& acc, const bf
     __syncthreads();
 }
 
+// the MFMAs of ONE K-step (64 wide) from a landed stage, reads interleaved as above
+__device__ __forceinline__ void gemm256_compute_il(gemm256_acc_t& acc, const char* tA, const char* tW, int arow,
+                                                   int wrow, int fq) {
+    bf16x8 w[4], a0, a1, wx[4], b0, b1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = g256_frag(tW, wrow + j * 16, 0, fq);
+    a0 = g256_frag(tA, arow, 0, fq);
+    a1 = g256_frag(tA, arow + 16, 0, fq);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+                b0 = g256_frag(tA, arow + (2 * g + 2) * 16, kk, fq);
+                b1 = g256_frag(tA, arow + (2 * g + 3) * 16, kk, fq);
+            } else if (kk == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wx[j] = g256_frag(tW, wrow + j * 16, 1, fq);
+                b0 = g256_frag(tA, arow, 1, fq);
+                b1 = g256_frag(tA, arow + 16, 1, fq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[2 * g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a0, acc[2 * g][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[2 * g + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a1, acc[2 * g + 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = b0; a1 = b1;
+            if (g == 3 && kk == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = wx[j];
+            }
+        }
+    }
+}
+
 }  // namespace vr

@@ -99,6 +99,7 @@ struct SearchArgs {
 };
 int search_kprime(int k);            // candidates kept per (query, chunk); 0 if k unsupported
 int search_num_chunks(int64_t n_docs, int nq);
+int search_prepass_floats();         // floats of cand_scores per (padded) query the threshold pre-pass needs
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
 bool search_uses_256(int nq);         // more than 128 queries: main sweep on the 256^2 tile (search256.hip)
 hipError_t launch_sweep256(const SearchArgs& a, int kp, const float* thr, hipStream_t s);

@@ -130,44 +130,114 @@ __global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_t
     }
 }
 
-// pre-pass result -> per-query initial threshold: the KP-th best score over the sampled tiles
-// (or -inf when the sample holds fewer than KP rows)
+// ---- threshold pre-pass ----------------------------------------------------------------------
+// One workgroup = one sampled 128-doc tile x 128 queries: the plain GEMM tile, no candidate
+// machinery.  A lane holds 4 docs (its 4 row fragments) of each of its 16 query columns; it emits
+// the max of the 4, so a query gets 32 group maxima per tile, each over 4 DISTINCT docs.
+// search_thr_kernel folds the PRE_CHUNKS*32 = 256 maxima of a query to 64 (lane-local max of 4)
+// and sorts them once: the KP-th largest is <= the scores of KP distinct docs, i.e. a valid lower
+// bound of the query's global KP-th best score, and nearly as tight as the KP-th best of the
+// 1024-doc sample (the top KP rarely share a 16-doc group).
+constexpr int PRE_CHUNKS = 8;      // sampled tiles = 1024 rows
+constexpr int PRE_GROUPS = 32;     // group maxima per (query, tile)
+
+__global__ __launch_bounds__(256) void search_prepass_kernel(SearchArgs p, int q_tiles, int tile_step,
+                                                             float* __restrict__ gmax) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int chunk = blockIdx.x / q_tiles, q0 = (blockIdx.x % q_tiles) * 128;
+    const int doc0 = chunk * tile_step * 128;
+    gemm_acc_t acc;
+    gemm_zero(acc);
+    gemm_mainloop<true>(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (doc0 + wm * 64 + i * 16 + fr < p.n_docs) m = fmaxf(m, acc[i][j][r]);
+            const int qn = q0 + wn * 64 + j * 16 + fq * 4 + r;
+            gmax[((size_t)qn * PRE_CHUNKS + chunk) * PRE_GROUPS + wm * 16 + fr] = m;
+        }
+    }
+}
+
 template <int KP>
-__global__ __launch_bounds__(256) void search_thr_kernel(SearchArgs p, int n_chunks_pre, int nq_pad,
+__global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict__ gmax, int nq_pad,
                                                          float* __restrict__ thr) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq_pad) return;
-    const int total = n_chunks_pre * KP;
-    const float* cs = p.cand_scores + (size_t)q * total;
-    const int* ci = p.cand_ids + (size_t)q * total;
-    uint64_t best = KEY_NONE;
-    for (int base = 0; base < total; base += 64) {
-        const int e = base + lane;
-        uint64_t key = KEY_NONE;
-        if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
-        best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
-    }
-    const uint64_t kth = shfl_u64(best, KP - 1);
-    if (lane == 0) thr[q] = (kth == KEY_NONE) ? -INFINITY : orderable_f32((uint32_t)(kth >> 32));
+    const float* g = gmax + (size_t)q * PRE_CHUNKS * PRE_GROUPS;
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < PRE_CHUNKS * PRE_GROUPS / 64; ++t) m = fmaxf(m, g[t * 64 + lane]);
+    const uint64_t sorted = wave_sort_desc((uint64_t)f32_orderable(m) << 32);
+    const uint64_t kth = shfl_u64(sorted, KP - 1);
+    if (lane == 0) thr[q] = orderable_f32((uint32_t)(kth >> 32));
 }
 
 constexpr int MERGE_MAXV = 10;
+constexpr int MERGE_CAP = 256;     // survivor buffer per query (merge kernel)
 
 template <int KP>
 __global__ __launch_bounds__(256) void search_merge_kernel(SearchArgs p) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= p.nq) return;
+    const int wave = threadIdx.x >> 6;
     const int total = p.n_chunks * KP;
     const float* cs = p.cand_scores + (size_t)q * total;
     const int* ci = p.cand_ids + (size_t)q * total;
+    // 1. lower bound of the global KP-th best key from the chunk HEADS (every chunk list is sorted,
+    //    valid entries first): lane-local max over its chunks, one sort, KP-th largest.  At least
+    //    KP distinct entries are >= it; KEY_NONE (fewer than KP non-empty lanes) keeps everything.
+    uint64_t head = KEY_NONE;
+    for (int c = lane; c < p.n_chunks; c += 64) {
+        const int id = ci[c * KP];
+        if (id >= 0) { const uint64_t key = make_key(cs[c * KP], (uint32_t)id); head = key > head ? key : head; }
+    }
+    const uint64_t thr = shfl_u64(wave_sort_desc(head), KP - 1);
+    // 2. walk the lists (lane = chunk) while they stay >= thr, appending survivors to LDS
+    __shared__ uint64_t surv[4][MERGE_CAP];
+    int n = 0;
+    for (int c0 = 0; c0 < p.n_chunks; c0 += 64) {
+        const int c = c0 + lane;
+        bool live = c < p.n_chunks;
+        for (int s = 0; s < KP; ++s) {
+            uint64_t key = KEY_NONE;
+            if (live) {
+                const int id = ci[c * KP + s];
+                if (id >= 0) key = make_key(cs[c * KP + s], (uint32_t)id);
+                live = key != KEY_NONE && key >= thr;
+            }
+            const unsigned long long bal = __ballot(live);
+            if (!bal) break;
+            if (live) {
+                const int pos = n + __popcll(bal & ((1ull << lane) - 1));
+                if (pos < MERGE_CAP) surv[wave][pos] = key;
+            }
+            n += __popcll(bal);
+        }
+    }
     uint64_t best = KEY_NONE;
-    for (int base = 0; base < total; base += 64) {
-        const int e = base + lane;
-        uint64_t key = KEY_NONE;
-        if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
-        best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
+    if (n <= MERGE_CAP) {
+        // 3. usually <= 64 survivors: one sort
+        for (int base = 0; base < n; base += 64) {
+            const uint64_t key = (base + lane < n) ? surv[wave][base + lane] : KEY_NONE;
+            best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
+        }
+    } else {
+        // massive ties at the threshold: merge every entry
+        for (int base = 0; base < total; base += 64) {
+            const int e = base + lane;
+            uint64_t key = KEY_NONE;
+            if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
+            best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
+        }
     }
     // fp32 re-scoring of the best KP candidates (lane c < KP owns candidate c)
     const int nv = p.dim >> 2;
@@ -211,6 +281,8 @@ int search_kprime(int k) {
     return 0;
 }
 
+int search_prepass_floats() { return PRE_CHUNKS * PRE_GROUPS; }
+
 bool search_uses_256(int nq) {
     static int force = -1;           // tuning aid: VR_SEARCH_TILE=128 keeps every search on the 128^2 sweep
     if (force < 0) { const char* e = getenv("VR_SEARCH_TILE"); force = (e && atoi(e) == 128) ? 1 : 0; }
@@ -234,8 +306,6 @@ int search_num_chunks(int64_t n_docs, int nq) {
     return chunks;
 }
 
-constexpr int PRE_CHUNKS = 8;      // pre-pass: 8 sampled tiles = 1024 rows
-
 template <int KP>
 static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     const int q_tiles = (a.nq + 127) / 128;
@@ -246,13 +316,13 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     hipError_t e;
     const float* thr = nullptr;
     if (a.thr_init && n_tiles >= 8 * PRE_CHUNKS) {
-        SearchArgs pre = a;
-        pre.n_chunks = PRE_CHUNKS;
-        const int step = n_tiles / PRE_CHUNKS;
-        hipLaunchKernelGGL(k, dim3(PRE_CHUNKS * q_tiles), dim3(256), SWEEP_SMEM, s, pre, q_tiles, 1, step,
-                           (const float*)nullptr);
+        static bool pattr = false;
+        if (!pattr) { (void)hipFuncSetAttribute((const void*)search_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); pattr = true; }
+        float* gmax = a.cand_scores;                   // [nq_pad128][PRE_CHUNKS][PRE_GROUPS], dead before the sweep writes
+        hipLaunchKernelGGL(search_prepass_kernel, dim3(PRE_CHUNKS * q_tiles), dim3(256), GEMM_SMEM_BYTES, s, a, q_tiles,
+                           n_tiles / PRE_CHUNKS, gmax);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(search_thr_kernel<KP>, dim3(q_tiles * 32), dim3(256), 0, s, pre, PRE_CHUNKS, q_tiles * 128,
+        hipLaunchKernelGGL(search_thr_kernel<KP>, dim3(q_tiles * 32), dim3(256), 0, s, (const float*)gmax, q_tiles * 128,
                            a.thr_init);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         thr = a.thr_init;

@@ -2,6 +2,7 @@
 // keys and the 64-lane bitonic network.
 #pragma once
 #include "common.h"
+#include "wave_sort.h"
 
 namespace vr {
 
@@ -33,28 +34,15 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// 64-lane bitonic sort, descending: lane 0 ends with the largest key.
-__device__ __forceinline__ uint64_t wave_bitonic_desc(uint64_t key, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint64_t other = shfl_xor_u64(key, j);
-            const bool desc = (lane & k) == 0;
-            const bool low = (lane & j) == 0;
-            const bool keep_max = (desc == low);
-            const uint64_t mx = key > other ? key : other, mn = key > other ? other : key;
-            key = keep_max ? mx : mn;
-        }
-    }
-    return key;
-}
-// top-64 of (sorted-desc `cur`) U (arbitrary `fresh`), sorted descending
-__device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fresh, int lane) {
-    fresh = wave_bitonic_desc(fresh, lane);
-    const uint64_t rev = shfl_u64(fresh, 63 - lane);
-    const uint64_t best = cur > rev ? cur : rev;      // bitonic sequence holding the top 64
-    return wave_bitonic_desc(best, lane);
+// 64-lane bitonic sort, descending: lane 0 ends with the largest key (wave_sort.h: DPP /
+// permlane-swap exchanges, no LDS round trips).
+__device__ __forceinline__ uint64_t wave_bitonic_desc(uint64_t key, int /*lane*/) { return wave_sort_desc(key); }
+// top-64 of (sorted-desc `cur`) U (arbitrary `fresh`), sorted descending: sort `fresh` ASCENDING
+// (descending sort of the complemented keys); max(cur[i], fresh_asc[i]) is then a bitonic
+// sequence holding the 64 largest keys, which the last 6 stages of the network order.
+__device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fresh, int /*lane*/) {
+    const uint64_t asc = ~wave_sort_desc(~fresh);
+    return wave_bitonic_finish_desc(cur > asc ? cur : asc);
 }
 
 }  // namespace vr
