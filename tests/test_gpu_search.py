@@ -57,6 +57,36 @@ def test_search_ties_and_duplicates():
     assert list(ids[1, :2]) == [11, 900]
 
 
+@pytest.mark.parametrize("nq", [7, 200])
+def test_search_adversarial_orders(nq):
+    """Corpora that defeat the threshold pre-pass: (a) every row identical (all scores tie: the
+    lowest ids must win, every candidate list overflows), (b) scores increasing with the row id
+    (each new row beats everything before it).  nq=200 runs the 256-tile sweep (wave-owned
+    half-lists + own compaction + the merge fallback), nq=7 the 128-tile one."""
+    dim, nd, k = 64, 20000, 10
+    rng = np.random.default_rng(5)
+    v = _unit(1, dim, 9)[0]
+    Q = v[None, :] + 0.02 * rng.standard_normal((nq, dim)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    # (a) identical rows
+    C = np.tile(_unit(1, dim, 6), (nd, 1))
+    ix = HipIndex(dim, nd); ix.add(C)
+    sc, ids = ix.search(Q, k)
+    assert np.array_equal(ids, np.tile(np.arange(k), (nq, 1)))
+    np.testing.assert_allclose(sc, (Q @ C[0])[:, None].repeat(k, 1), atol=1e-5)
+    # (b) random unit rows sorted by their score against the queries' common direction: for every
+    #     query the scores rise (almost) monotonically with the row id
+    C = _unit(nd, dim, 8)
+    C = C[np.argsort(C @ v, kind="stable")]
+    ix = HipIndex(dim, nd); ix.add(C)
+    sc, ids = ix.search(Q, k)
+    rs, ri = O.search_topk(Q, C, k)
+    np.testing.assert_allclose(sc, rs, atol=1e-5, rtol=0)
+    for q, c in np.argwhere(ids != ri):
+        j = int(np.flatnonzero(ri[q] == ids[q, c])[0]) if ids[q, c] in ri[q] else -1
+        assert j >= 0 and abs(rs[q, j] - rs[q, c]) < 3e-7, (q, c)
+
+
 def test_search_golden_reference(golden_dir):
     """Same corpus/queries as the REFERENCE run in tests/golden/retrieve.npz: the global top-5
     must be the reference's (distributed_parallel_retrieve over 3 shards)."""

@@ -1071,7 +1071,7 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
         }
         a.cand_scores = ix->cs.as<float>(); a.cand_ids = ix->ci.as<int>();
         if (search_uses_256(nq)) {
-            const int64_t kneed = nqp * a.n_chunks * 64;
+            const int64_t kneed = nqp * a.n_chunks * 128;      // [q][chunk][2 halves][64]
             if (ix->kcap < kneed) { VRCHK(ix->ck.alloc((size_t)kneed * 8)); ix->kcap = kneed; }
             a.cand_keys = ix->ck.as<unsigned long long>();
         }

@@ -95,7 +95,7 @@ struct SearchArgs {
     float* cand_scores; int* cand_ids; int n_chunks;   // workspace [nq_pad][n_chunks][KP]
     float* out_scores; int64_t* out_ids;               // [nq][k]
     float* thr_init;                                   // workspace [nq_pad] or null (no pre-pass)
-    unsigned long long* cand_keys;                     // 256-tile sweep scratch [nq_pad256][n_chunks][64] or null
+    unsigned long long* cand_keys;                     // 256-tile sweep scratch [nq_pad256][n_chunks][2][64] or null
 };
 int search_kprime(int k);            // candidates kept per (query, chunk); 0 if k unsupported
 int search_num_chunks(int64_t n_docs, int nq);

@@ -180,8 +180,6 @@ __global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict
     if (lane == 0) thr[q] = orderable_f32((uint32_t)(kth >> 32));
 }
 
-constexpr int MERGE_MAXV = 10;
-constexpr int MERGE_CAP = 256;     // survivor buffer per query (merge kernel)
 
 template <int KP>
 __global__ __launch_bounds__(256) void search_merge_kernel(SearchArgs p) {
@@ -239,39 +237,7 @@ __global__ __launch_bounds__(256) void search_merge_kernel(SearchArgs p) {
             best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
         }
     }
-    // fp32 re-scoring of the best KP candidates (lane c < KP owns candidate c)
-    const int nv = p.dim >> 2;
-    f32x4 qv[MERGE_MAXV];
-    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
-#pragma unroll
-    for (int i = 0; i < MERGE_MAXV; ++i) {
-        const int c = lane + i * 64;
-        qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    uint64_t exact = KEY_NONE;
-    for (int c = 0; c < KP; ++c) {
-        const uint64_t key = shfl_u64(best, c);
-        if (key == KEY_NONE) break;                      // wave-uniform
-        const uint32_t id = ~(uint32_t)key;
-        const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id * p.dim);
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < MERGE_MAXV; ++i) {
-            const int cc = lane + i * 64;
-            if (cc < nv) {
-                const f32x4 d = dr[cc];
-                s += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
-            }
-        }
-        s = wave_sum(s);
-        if (lane == c) exact = make_key(s, id);
-    }
-    exact = wave_bitonic_desc(exact, lane);
-    if (lane < p.k) {
-        const bool ok = exact != KEY_NONE;
-        p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(exact >> 32)) : -INFINITY;
-        p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)exact) : (int64_t)-1;
-    }
+    rescore_emit<KP>(p, q, best, lane);
 }
 
 int search_kprime(int k) {
@@ -327,9 +293,8 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         if ((e = hipGetLastError()) != hipSuccess) return e;
         thr = a.thr_init;
     }
-    if (search_uses_256(a.nq)) {
-        if ((e = launch_sweep256(a, KP, thr, s)) != hipSuccess) return e;
-    } else {
+    if (search_uses_256(a.nq)) return launch_sweep256(a, KP, thr, s);       // sweep + its own merge
+    {
         const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
         hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc, 1, thr);
         if ((e = hipGetLastError()) != hipSuccess) return e;

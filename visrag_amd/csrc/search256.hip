@@ -1,15 +1,26 @@
-// Search sweep on the 256 x 256 x 64 tile (8 waves, 128 KiB of LDS stages): the main sweep of
-// vr_index_search for more than 128 queries.
+// Search sweep on the 256 x 256 x 64 tile (8 waves, 128 KiB of LDS stages) + its merge kernel:
+// the main sweep of vr_index_search for more than 128 queries.
 //
-// Same algorithm as search_sweep_kernel (search.hip) — fused similarity GEMM, per-query running
-// threshold, 64-entry candidate buffers compacted by a 64-lane bitonic sort — but on the GEMM
-// main loop that reaches ~1.2 PFLOP/s instead of the 128^2 loop that, with 64 KiB of candidate
-// buffers next to its stages, ran one 4-wave workgroup per CU (390 TFLOP/s).  The LDS is all
-// taken by the operand stages, so the candidate buffers live in a global scratch
-// ([query][chunk][64] keys, L2-resident: ~30 appends per (query, chunk) after the threshold
-// pre-pass); only thresholds and counters stay in LDS.
+// Same idea as search_sweep_kernel (search.hip) — fused similarity GEMM, scores filtered in
+// registers against a per-query threshold, survivors kept as (score, id) keys, exact top-k by a
+// 64-lane bitonic network — on the GEMM main loop that reaches ~1.1 PFLOP/s here (the 128^2 loop
+// with 64 KiB of LDS candidate buffers ran one 4-wave workgroup per CU: 390 TFLOP/s).
+//
 //   workgroup = (doc chunk, 256-query tile); A = index rows (docs), W = query rows.
 //   acc[i][j][r]: doc = wm*128 + i*16 + fr, query = wn*64 + j*16 + fq*4 + r.
+//
+// Candidate lists.  The LDS is taken by the operand stages, so survivors go to a global scratch
+// (L2-resident; ~30 appends per (query, chunk) after the threshold pre-pass).  Every wave OWNS the
+// half-lists [query][chunk][wm][64] of its 64 queries: the 16 lanes of a quad-row group (same fq)
+// hold the same 16 query columns, so a wave-wide ballot gives every lane of the group both its
+// slot (popcount of the group's lower lanes) and the group's new length — the list lengths live
+// replicated in registers (16 byte-counters per lane), no atomics, no LDS traffic, no barriers in
+// the epilogue.  A half-list that passes 48 entries (adversarial orders; ~never after the
+// pre-pass) is compacted by its wave alone: sort, keep KP, raise the query's threshold.
+// The lists are emitted UNSORTED with their lengths; search_merge256_kernel bounds the global
+// KP-th best from lane-local maxima, filters, sorts the few survivors once and re-scores in fp32.
+#include <cstdlib>
+
 #include "gemm_core.h"
 #include "gemm_core_il.h"
 #include "kernels.h"
@@ -17,9 +28,11 @@
 
 namespace vr {
 
+constexpr int HL_CAP = 64;          // slots per half-list
+constexpr int HL_TRIG = 48;         // compact a half-list longer than this (a strip adds <= 16)
+
 struct Sweep256Lds {
     float thr[256];
-    int cnt[256];
 };
 constexpr int SWEEP256_SMEM = G256_SMEM_BYTES + (int)sizeof(Sweep256Lds) + 256;   // + touch dump
 
@@ -50,7 +63,7 @@ __device__ __forceinline__ void stage256(const char* base, const uint32_t (&off)
 
 template <int KP>
 __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk,
-                                                              const float* __restrict__ thr_init) {
+                                                              const float* __restrict__ thr_init, int debug) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Sweep256Lds& L = *reinterpret_cast<Sweep256Lds*>(smem + G256_SMEM_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,55 +77,65 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
     const int n_tiles = (int)((p.n_docs + 255) / 256);
     const int tile_lo = chunk * tiles_per_chunk;
     const int tile_hi = min(n_tiles, tile_lo + tiles_per_chunk);
-    unsigned long long* gc = p.cand_keys + ((size_t)q0 * p.n_chunks + chunk) * SRCH_CAP;
-    const size_t gq = (size_t)p.n_chunks * SRCH_CAP;           // stride between queries
+    // half-list of query qq (0..255 in this tile), owner half wm: gw + qq * gq
+    unsigned long long* gw = p.cand_keys + (((size_t)q0 * p.n_chunks + chunk) * 2 + wm) * HL_CAP;
+    const size_t gq = (size_t)p.n_chunks * 2 * HL_CAP;
 
     if (tid < 256) {
         float t0 = (thr_init && q0 + tid < p.nq) ? thr_init[q0 + tid] : -INFINITY;
-        if (q0 + tid >= p.nq) t0 = INFINITY;                   // padding queries never collect candidates
+        if (q0 + tid >= p.nq || (debug & 1)) t0 = INFINITY;    // padding queries never collect candidates
         L.thr[tid] = t0;
-        L.cnt[tid] = 0;
     }
     __syncthreads();
 
-    // one wave compacts the buffers of its 32 queries: sort, keep the best KP, raise thr.
-    // Four queries per round: the four key loads (L2 round trips) fly together and the four
-    // independent sort networks interleave on the VALU.
-    auto compact = [&](bool force, int wave, int lane) {
-        const int c_l = L.cnt[wave * 32 + (lane & 31)];
-        unsigned long long todo = __ballot((lane < 32) && (force ? c_l > 0 : c_l > SRCH_TRIG));
-        while (todo) {
-            int qq[4], c[4];
-            uint64_t key[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int src = todo ? __ffsll((long long)todo) - 1 : -1;
-                todo &= todo - 1;                                   // (0 stays 0)
-                qq[u] = src < 0 ? -1 : wave * 32 + src;
-                c[u] = src < 0 ? 0 : __shfl(c_l, src, 64);
-                key[u] = (lane < c[u]) ? ld_key(gc + (size_t)qq[u] * gq + lane) : KEY_NONE;
+    // lengths of this wave's half-lists, replicated over the 16 lanes of a group:
+    // byte r of c8[j] = length of the list of query wn*64 + j*16 + fq*4 + r
+    uint32_t c8[4] = {0u, 0u, 0u, 0u};
+
+    // rare: a half-list of this wave passed HL_TRIG -> the wave alone sorts it, keeps the best KP and
+    // raises the query's threshold.  A runtime loop over the 16 (j, r) columns (kept rolled: unrolled
+    // into the 8 strips it bloated the epilogue until the strip loop no longer unrolled).
+    auto compact_own = [&](int lane_e, int wave_e) {
+        const int fr_e = lane_e & 15, fq_e = lane_e >> 4, wn_e = wave_e & 3;
+        __threadfence_block();                                  // own stores visible to own loads
+#pragma nounroll
+        for (int jr = 0; jr < 16; ++jr) {
+            const int j = jr >> 2, r = jr & 3;
+            const uint32_t cw = j == 0 ? c8[0] : j == 1 ? c8[1] : j == 2 ? c8[2] : c8[3];
+            const int c_l = (int)((cw >> (8 * r)) & 0xFFu);
+            unsigned long long todo = __ballot(c_l > HL_TRIG && fr_e == 0);   // one bit per group
+            uint32_t nw = cw;
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;                // lane fq*16
+                todo &= todo - 1;
+                const int qq = wn_e * 64 + j * 16 + (src >> 4) * 4 + r;
+                const int c = __shfl(c_l, src, 64);
+                unsigned long long* row = gw + (size_t)qq * gq;
+                uint64_t key = (lane_e < c) ? ld_key(row + lane_e) : KEY_NONE;
+                key = wave_sort_desc(key);
+                if (lane_e < KP) st_key(row + lane_e, key);
+                const int keep = min(c, KP);
+                if (lane_e == KP - 1 && c >= KP) {
+                    const float t = orderable_f32((uint32_t)(key >> 32));
+                    if (t > L.thr[qq]) L.thr[qq] = t;              // (the partner half may race: both bounds are valid)
+                }
+                if (fq_e == (src >> 4)) nw = (nw & ~(0xFFu << (8 * r))) | ((uint32_t)keep << (8 * r));
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) key[u] = wave_sort_desc(key[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (qq[u] < 0) continue;                            // wave-uniform
-                if (lane < KP) st_key(gc + (size_t)qq[u] * gq + lane, key[u]);
-                if (lane == KP - 1 && c[u] >= KP) L.thr[qq[u]] = orderable_f32((uint32_t)(key[u] >> 32));
-                if (lane == 0) L.cnt[qq[u]] = min(c[u], KP);
-            }
+            c8[0] = j == 0 ? nw : c8[0];
+            c8[1] = j == 1 ? nw : c8[1];
+            c8[2] = j == 2 ? nw : c8[2];
+            c8[3] = j == 3 ? nw : c8[3];
         }
+        __threadfence_block();
     };
 
     // ---- one K-step stream over all tiles of the chunk -----------------------------------------
-    // The index rows come from HBM, not from L2: with two LDS stages the LDS-DMA of step s+1 has
-    // one step (~1.1 us) to land, less than an HBM round trip under load, and every K-step stalled
-    // (measured: 680 TFLOP/s against 1.2 PFLOP/s for the same loop on L2-resident operands).
-    // Each step therefore also TOUCHES the index lines of step s+3 (one dword per thread, 2 per
-    // 128-B line, LDS-DMA'd into a dump area so no register is written): the line is in L2 when
-    // the real DMA asks for it two steps later.  The touch is the youngest VMEM op of the step, so
-    // `vmcnt(1)` waits for the stage without waiting for the touch.  The DMA of the next tile's
-    // first step is issued before the filter epilogue of the current tile.
+    // Each step also TOUCHES the index lines of step s+3 (one dword per thread, 2 per 128-B line,
+    // LDS-DMA'd into a dump area so no register is written), so the index rows — which come from
+    // HBM, not from L2 — are on their way two steps before the real DMA asks for them.  The touch
+    // is the youngest VMEM op of the step, so `vmcnt(1)` waits for the stage without waiting for
+    // the touch.  The DMA of the next tile's first step is issued before the filter epilogue of
+    // the current tile.
     const char* A = (const char*)p.index_bf16;
     const char* W = (const char*)p.q_bf16 + (size_t)q0 * p.dim * 2;
     const int nk = p.dim / GEMM_BK;
@@ -164,60 +187,134 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
             gemm256_compute_il(acc, cur, cur + G256_TILE_BYTES, arow, wrow, fq);
             sp ^= 1;
         }
-        // ---- filter epilogue.  Everything it derives from the lane / wave id is recomputed here
-        // from laundered copies: hoisted above the K-loop those values spilled the main loop.
+        // ---- filter epilogue (no workgroup barrier).  Everything it derives from the lane / wave
+        // id is recomputed here from laundered copies: hoisted above the K-loop those values
+        // spilled the main loop.
         int lane_e = lane, wave_e = wave;
         asm volatile("" : "+v"(lane_e), "+s"(wave_e));
         const int fr_e = lane_e & 15, fq_e = lane_e >> 4, wm_e = wave_e >> 2, wn_e = wave_e & 3;
+        const uint32_t below = (1u << fr_e) - 1u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int doc = doc0 + wm_e * 128 + i * 16 + fr_e;
-            bool any = false;
-            if (doc < p.n_docs) {
+            const bool valid = doc < p.n_docs;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int qn = wn_e * 64 + j * 16 + fq_e * 4;
-                    const f32x4 th = *reinterpret_cast<const f32x4*>(&L.thr[qn]);
+            for (int j = 0; j < 4; ++j) {
+                const int qn = wn_e * 64 + j * 16 + fq_e * 4;
+                const f32x4 th = *reinterpret_cast<const f32x4*>(&L.thr[qn]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float s = acc[i][j][r];
-                        if (s >= th[r]) {
-                            const int qq = qn + r;
-                            // LDS counter bump in asm: as a builtin the compiler puts s_waitcnt vmcnt(0)
-                            // in front of it (LDS-DMA alias rule), i.e. every append waited for the
-                            // previous append's global store and for the next tile's in-flight stage
-                            int pos;
-                            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                         : "=v"(pos) : "v"((uint32_t)(uintptr_t)VR_LDS(&L.cnt[qq])), "v"(1) : "memory");
-                            st_key(gc + (size_t)qq * gq + pos, make_key(s, (uint32_t)doc));
-                            any = true;
+                for (int r = 0; r < 4; ++r) {
+                    const float s = acc[i][j][r];
+                    const bool pass = valid && s >= th[r];
+                    const unsigned long long bal = __ballot(pass);
+                    if (bal) {                                  // wave-uniform, ~70 % of the (j, r)
+                        const uint32_t grp = (uint32_t)(bal >> (fq_e * 16)) & 0xFFFFu;
+                        if (pass) {
+                            const int pos = (int)((c8[j] >> (8 * r)) & 0xFFu) + __popc(grp & below);
+                            st_key(gw + (size_t)(qn + r) * gq + pos, make_key(s, (uint32_t)doc));
                         }
+                        c8[j] += (uint32_t)__popc(grp) << (8 * r);
                     }
                 }
             }
-            // a query gains at most 2 x 16 candidates per strip, so TRIG + 32 <= CAP never overflows
-            if (__syncthreads_or(any)) {
-                compact(false, wave_e, lane_e);
-                __syncthreads();
+            // ---- rare: one of this wave's half-lists passed HL_TRIG -> the wave compacts it
+            bool over = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) over |= ((c8[j] + 0x01010101u * (127 - HL_TRIG)) & 0x80808080u) != 0u;
+            if (__any(over)) compact_own(lane_e, wave_e);
+        }
+    }
+    // ---- list lengths: [query][chunk][wm]
+    if (fr == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = wn * 64 + j * 16 + fq * 4 + r;
+                p.cand_ids[((size_t)(q0 + qq) * p.n_chunks + chunk) * 2 + wm] = (int)((c8[j] >> (8 * r)) & 0xFFu);
             }
         }
     }
-    __syncthreads();
-    compact(true, wave, lane);
-    __syncthreads();
-    // emit [query][chunk][KP] (score, id); unused slots: -inf / -1
-    for (int e = tid; e < 256 * KP; e += 512) {
-        const int qq = e / KP, s = e % KP;
-        const size_t o = ((size_t)(q0 + qq) * p.n_chunks + chunk) * KP + s;
-        if (s < L.cnt[qq]) {
-            const uint64_t key = ld_key(gc + (size_t)qq * gq + s);
-            p.cand_scores[o] = orderable_f32((uint32_t)(key >> 32));
-            p.cand_ids[o] = (int)(~(uint32_t)key);
-        } else {
-            p.cand_scores[o] = -INFINITY;
-            p.cand_ids[o] = -1;
+}
+
+// ---- merge: one wave per query over its n_chunks * 2 unsorted half-lists --------------------
+//  1. lane l takes the max over its own lists (l, l + 64, ...): 64 maxima over DISJOINT entry
+//     sets; the KP-th largest of them is <= KP distinct entries, i.e. a lower
+//     bound of the query's global KP-th best key (KEY_NONE when fewer than KP lanes saw a key);
+//  2. entries >= that bound are appended to LDS (ballot compaction) — typically ~20 of ~1900;
+//  3. one sort (or, for > MERGE_CAP survivors = massive ties, a merge over everything);
+//  4. fp32 re-scoring + final sort (rescore_emit).
+template <int KP>
+__global__ __launch_bounds__(256) void search_merge256_kernel(SearchArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= p.nq) return;
+    const int lists = p.n_chunks * 2;
+    const int* cnts = p.cand_ids + (size_t)q * lists;
+    const unsigned long long* keys = p.cand_keys + (size_t)q * lists * HL_CAP;
+    __shared__ uint64_t surv[4][MERGE_CAP];
+
+    // lane = list: every lane walks its own list(s), four keys (two 16-B loads) per round
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    uint64_t m = KEY_NONE;
+    for (int l0 = 0; l0 < lists; l0 += 64) {
+        const int l = l0 + lane;
+        const int c = l < lists ? cnts[l] : 0;
+        const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)min(l, lists - 1) * HL_CAP);
+        for (int e = 0; e < c; e += 4) {
+            const u64x2 a = row[e >> 1], b2 = row[(e >> 1) + 1];      // (slots past c are never read back)
+            const uint64_t k0 = a[0], k1 = e + 1 < c ? a[1] : KEY_NONE;
+            const uint64_t k2 = e + 2 < c ? b2[0] : KEY_NONE, k3 = e + 3 < c ? b2[1] : KEY_NONE;
+            const uint64_t x = k0 > k1 ? k0 : k1, y = k2 > k3 ? k2 : k3;
+            const uint64_t z = x > y ? x : y;
+            m = z > m ? z : m;
         }
     }
+    const uint64_t thr = shfl_u64(wave_sort_desc(m), KP - 1);
+
+    int n = 0;
+    for (int l0 = 0; l0 < lists; l0 += 64) {
+        const int l = l0 + lane;
+        const int c = l < lists ? cnts[l] : 0;
+        int cmax = c;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+        const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)min(l, lists - 1) * HL_CAP);
+        for (int e = 0; e < cmax; e += 4) {                          // wave-uniform trip count (ballots inside)
+            uint64_t k4[4] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+            if (e < c) {
+                const u64x2 a = row[e >> 1], b2 = row[(e >> 1) + 1];
+                k4[0] = a[0];
+                k4[1] = e + 1 < c ? a[1] : KEY_NONE;
+                k4[2] = e + 2 < c ? b2[0] : KEY_NONE;
+                k4[3] = e + 3 < c ? b2[1] : KEY_NONE;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = k4[u] != KEY_NONE && k4[u] >= thr;
+                const unsigned long long bal = __ballot(live);
+                if (live) {
+                    const int pos = n + __popcll(bal & ((1ull << lane) - 1));
+                    if (pos < MERGE_CAP) surv[wave][pos] = k4[u];
+                }
+                n += __popcll(bal);
+            }
+        }
+    }
+    uint64_t best = KEY_NONE;
+    if (n <= MERGE_CAP) {
+        for (int base = 0; base < n; base += 64) {
+            const uint64_t key = (base + lane < n) ? surv[wave][base + lane] : KEY_NONE;
+            best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+        }
+    } else {
+        for (int l = 0; l < lists; ++l) {
+            const int c = cnts[l];
+            const uint64_t key = (lane < c) ? keys[(size_t)l * HL_CAP + lane] : KEY_NONE;
+            best = (l == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+        }
+    }
+    rescore_emit<KP>(p, q, best, lane);
 }
 
 template <int KP>
@@ -228,10 +325,17 @@ static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s)
     auto k = search_sweep256_kernel<KP>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEP256_SMEM); attr = true; }
-    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr);
+    static int debug = -1;     // tuning aid: VR_SWEEP_DEBUG=1 rejects every score (GEMM + scan floor of the sweep)
+    if (debug < 0) { const char* e = getenv("VR_SWEEP_DEBUG"); debug = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr, debug);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(search_merge256_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
+// sweep + merge of the 256-tile path; cand_keys: [nq_pad256][n_chunks][2][64] keys,
+// cand_ids: [nq_pad256][n_chunks][2] list lengths
 hipError_t launch_sweep256(const SearchArgs& a, int kp, const float* thr, hipStream_t s) {
     if (!a.cand_keys || a.n_chunks % 8) return hipErrorInvalidValue;
     switch (kp) {

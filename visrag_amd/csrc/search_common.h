@@ -2,6 +2,7 @@
 // keys and the 64-lane bitonic network.
 #pragma once
 #include "common.h"
+#include "kernels.h"
 #include "wave_sort.h"
 
 namespace vr {
@@ -43,6 +44,61 @@ __device__ __forceinline__ uint64_t wave_bitonic_desc(uint64_t key, int /*lane*/
 __device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fresh, int /*lane*/) {
     const uint64_t asc = ~wave_sort_desc(~fresh);
     return wave_bitonic_finish_desc(cur > asc ? cur : asc);
+}
+
+constexpr int MERGE_MAXV = 10;     // dim <= 64 * 4 * MERGE_MAXV
+constexpr int MERGE_CAP = 256;     // survivor buffer per query (merge kernels)
+
+// Tail of both merge kernels: `best` holds the bf16-score top-KP keys of query q, sorted
+// descending (lane c = candidate c).  Re-score them against the fp32 index with exact fp32 dot
+// products (the ranking torch.topk over an fp32 matmul sees), sort on (score desc, id asc), emit
+// the top k.  Four candidates per round so that their row reads overlap (the rows are cold:
+// latency-, not bandwidth-bound).
+template <int KP>
+__device__ __forceinline__ void rescore_emit(const SearchArgs& p, int q, uint64_t best, int lane) {
+    const int nv = p.dim >> 2;
+    f32x4 qv[MERGE_MAXV];
+    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
+#pragma unroll
+    for (int i = 0; i < MERGE_MAXV; ++i) {
+        const int c = lane + i * 64;
+        qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    uint64_t exact = KEY_NONE;
+    for (int c0 = 0; c0 < KP; c0 += 4) {
+        if (shfl_u64(best, c0) == KEY_NONE) break;       // wave-uniform; keys are sorted, NONE last
+        float s[4];
+        uint32_t id[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t key = shfl_u64(best, c0 + u);
+            ok[u] = key != KEY_NONE;
+            id[u] = ok[u] ? ~(uint32_t)key : 0u;        // row 0 is always readable
+            const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id[u] * p.dim);
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < MERGE_MAXV; ++i) {
+                const int cc = lane + i * 64;
+                if (cc < nv) {
+                    const f32x4 d = dr[cc];
+                    a += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
+                }
+            }
+            s[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t = wave_sum(s[u]);
+            if (ok[u] && lane == c0 + u) exact = make_key(t, id[u]);
+        }
+    }
+    exact = wave_sort_desc(exact);
+    if (lane < p.k) {
+        const bool ok = exact != KEY_NONE;
+        p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(exact >> 32)) : -INFINITY;
+        p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)exact) : (int64_t)-1;
+    }
 }
 
 }  // namespace vr
