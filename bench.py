@@ -173,15 +173,29 @@ def main():
     dom = max(gemm_like, key=lambda k: gemm_like[k]["ms"])
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    kernel_names = {"vit_qkv": "vr::gemm256_bf16_kernel<0, 0> (EPI_BF16; ViT qkv, 256x256 tile)",
+    kernel_names = {"vit_qkv": "vr::gemm256_bf16_kernel<0, 4> (EPI_BF16; ViT qkv, 256x256 tile)",
                     "vit_attn": "vr::attention_kernel<72, 2> (ViT self-attention)",
                     "vit_proj": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT attn proj, 256x192 tile)",
-                    "vit_fc1": "vr::gemm256_bf16_kernel<1, 0> (EPI_GELU; ViT MLP fc1, 256x256 tile)",
+                    "vit_fc1": "vr::gemm256_bf16_kernel<1, 4> (EPI_GELU; ViT MLP fc1, 256x256 tile, interleaved-read main loop)",
                     "vit_fc2": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT MLP fc2, 256x192 tile)"}
     roofline = {"bound": "mfma", "kernel": kernel_names[dom], "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
                 "flops_per_launch": d["flops"] / d["launches"], "traffic": None}
+    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
+    # the figure is the committed rocprofv3 --pmc measurement of the same kernel on the same
+    # workload (tools/pmc_traffic.sh -> profiles/rNN_traffic.json); null if none is committed.
+    try:
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+        tj = json.load(open(tfiles[-1]))
+        key = kernel_names[dom].split(" (")[0].replace("vr::", "")
+        hit = [v for k, v in tj.items() if key in k]
+        if hit:
+            roofline["traffic"] = round(hit[0])
+            roofline["traffic_source"] = os.path.basename(tfiles[-1]) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+    except Exception:
+        pass
     phases = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()}
     f_page = cfg.flops_page(1024, len(items[0].input_ids))
