@@ -129,6 +129,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_32) return launch_gemm32(a, epi, s);
     if (variant == GEMM_VARIANT_256P) return launch_gemm256p(a, epi, s);
+    if (variant == GEMM_VARIANT_256T) return launch_gemm256t(a, epi, s);
+    if (variant == GEMM_VARIANT_256W4) return launch_gemm256w4(a, epi, s);
     if (variant >= 20 && variant <= 26) return launch_gemm_ablate(a, variant, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel

@@ -1,0 +1,143 @@
+// 256 x 256 x 64 GEMM with FOUR waves, 128 x 128 per wave (variant 12).
+//
+// The 8-wave kernel's main loop is LDS-bandwidth bound: per K-step its waves read 8 x 24 KiB of
+// fragments (12 reads feed 32 MFMAs) and the LDS-DMA writes 64 KiB — 256 KiB through a 128 B/clk
+// LDS = 2048 clk, exactly the 2048 clk the 128 MFMAs of a SIMD take, with no slack for either.
+// One wave per SIMD with a 128 x 128 tile reads 16 fragments per 64 MFMAs (0.25 instead of 0.375
+// per MFMA): 128 + 64 KiB per step, 1536 clk.  The 256 accumulator registers live in AGPRs (one
+// wave per SIMD owns all 512 registers), the fragment reads of the next row strip are issued
+// before the current strip's 8 MFMAs.
+#include "gemm_core.h"
+#include "gemm_core_il.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace vr {
+
+typedef f32x4 acc_w4_t[8][8];
+
+__device__ __forceinline__ const char* w4_uptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+// this wave fills rows [wave*64, wave*64+64) of one 256 x 64 operand tile
+__device__ __forceinline__ void w4_stage(const char* base, const uint32_t (&off)[8], char* tile, int wave) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        uint32_t o = off[t];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(VR_GLOBAL(base + o), VR_LDS(tile + (wave * 64 + t * 8) * 128), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256w4_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (p.N + G256_BN - 1) / G256_BN;
+    const int tiles_m = (p.M + G256_BM - 1) / G256_BM;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int GM = p.raster_gm > 0 ? p.raster_gm : 1;
+    const int gsz = GM * tiles_n;
+    const int g = t / gsz, r = t % gsz;
+    const int gm = min(GM, tiles_m - g * GM);
+    const int m0 = __builtin_amdgcn_readfirstlane((g * GM + r % gm) * G256_BM);
+    const int n0 = __builtin_amdgcn_readfirstlane((r / gm) * G256_BN);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int arow = wm * 128 + fr, wrow = wn * 128 + fr;
+    const char* A = (const char*)p.A + (size_t)m0 * p.lda * 2;
+    const char* W = (const char*)p.W + (size_t)n0 * p.ldw * 2;
+    const int nk = p.K / GEMM_BK;
+    uint32_t offA[8], offW[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 64 + i * 8 + (lane >> 3);
+        const int kc8 = ((lane & 7) ^ (row & 7)) << 3;
+        offA[i] = (uint32_t)(row * p.lda + kc8) * 2u;
+        offW[i] = (uint32_t)(row * p.ldw + kc8) * 2u;
+    }
+    constexpr int SB = 2 * G256_TILE_BYTES;
+    w4_stage(A, offA, smem, wave);
+    w4_stage(W, offW, smem + G256_TILE_BYTES, wave);
+
+    acc_w4_t acc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* tA = smem + (kt & 1) * SB;
+        const char* tW = tA + G256_TILE_BYTES;
+        char* nxt = smem + ((kt + 1) & 1) * SB;
+        VR_WAIT_VM_BARRIER(0);                 // stage kt landed; every wave is done with stage kt-1
+        if (kt + 1 < nk) {
+            w4_stage(w4_uptr(A + (kt + 1) * (GEMM_BK * 2)), offA, nxt, wave);
+            w4_stage(w4_uptr(W + (kt + 1) * (GEMM_BK * 2)), offW, nxt + G256_TILE_BYTES, wave);
+        }
+        bf16x8 w[8], wx[8], a, an;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = g256_frag(tW, wrow + j * 16, 0, fq);
+        a = g256_frag(tA, arow, 0, fq);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // ---- request what the next strip needs
+                if (i < 7) an = g256_frag(tA, arow + (i + 1) * 16, kk, fq);
+                else if (kk == 0) an = g256_frag(tA, arow, 1, fq);
+                if (kk == 0 && i >= 4) {
+                    wx[2 * (i - 4)] = g256_frag(tW, wrow + 2 * (i - 4) * 16, 1, fq);
+                    wx[2 * (i - 4) + 1] = g256_frag(tW, wrow + (2 * (i - 4) + 1) * 16, 1, fq);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a, acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a = an;
+            }
+            if (kk == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = wx[j];
+            }
+        }
+    }
+
+    const int mrow = m0 + wm * 128 + fr, nb = n0 + wn * 128;
+    if constexpr (EPI == EPI_RESID) {
+        if (!p.rowmap) { gemm_epilogue_resid_tile<8, 8, 2>(acc, p, mrow, nb, fq); return; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        gemm_epilogue_row<EPI>(reinterpret_cast<f32x4(&)[4]>(acc[i][0]), p, mrow + i * 16, nb, fq);
+        gemm_epilogue_row<EPI>(reinterpret_cast<f32x4(&)[4]>(acc[i][4]), p, mrow + i * 16, nb + 64, fq);
+    }
+}
+
+template <int EPI>
+static hipError_t launch_t(GemmArgs a, hipStream_t s) {
+    const int tm = (a.M + G256_BM - 1) / G256_BM, tn = (a.N + G256_BN - 1) / G256_BN;
+    if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
+    auto k = gemm256w4_bf16_kernel<EPI>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr = true; }
+    hipLaunchKernelGGL(k, dim3(tm * tn), dim3(256), G256_SMEM_BYTES, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm256w4(const GemmArgs& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BF16: return launch_t<EPI_BF16>(a, s);
+        case EPI_GELU: return launch_t<EPI_GELU>(a, s);
+        case EPI_F32: return launch_t<EPI_F32>(a, s);
+        case EPI_RESID: return launch_t<EPI_RESID>(a, s);
+        case EPI_SWIGLU: return launch_t<EPI_SWIGLU>(a, s);
+        case EPI_ROPE: return launch_t<EPI_ROPE>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace vr

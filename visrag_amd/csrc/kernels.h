@@ -9,7 +9,7 @@ namespace vr {
 enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_SWIGLU = 4, EPI_ROPE = 5 };
 // GLDS/REG: 128x128 tile (LDS-DMA / register staging); 256: 256x256 8-wave tile (needs W and A
 // readable up to the next multiple of 256 rows); AUTO picks by M.
-enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1, GEMM_VARIANT_256 = 2, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_256P4 = 4, GEMM_VARIANT_256MID = 5, GEMM_VARIANT_256STAG = 6, GEMM_VARIANT_192 = 7, GEMM_VARIANT_32 = 8, GEMM_VARIANT_256IL = 9, GEMM_VARIANT_256P = 10 };
+enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1, GEMM_VARIANT_256 = 2, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_256P4 = 4, GEMM_VARIANT_256MID = 5, GEMM_VARIANT_256STAG = 6, GEMM_VARIANT_192 = 7, GEMM_VARIANT_32 = 8, GEMM_VARIANT_256IL = 9, GEMM_VARIANT_256P = 10, GEMM_VARIANT_256T = 11, GEMM_VARIANT_256W4 = 12 };
 
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M_pad][lda]
@@ -34,6 +34,8 @@ hipError_t launch_gemm192(const GemmArgs& a, int epilogue, hipStream_t s);
 hipError_t launch_gemm32(const GemmArgs& a, int epilogue, hipStream_t s);
 // persistent 256x256 kernel: one workgroup per CU walks the tile list (gemm256p.hip)
 hipError_t launch_gemm256p(const GemmArgs& a, int epilogue, hipStream_t s);
+hipError_t launch_gemm256t(const GemmArgs& a, int epilogue, hipStream_t s);   // 256^2 + L2 touch-ahead
+hipError_t launch_gemm256w4(const GemmArgs& a, int epilogue, hipStream_t s);  // 256^2, 4 waves x (128 x 128)
 // timing ablations of the 256-tile main loop (variants 20..23, invalid results; gemm_ablate.hip)
 hipError_t launch_gemm_ablate(const GemmArgs& a, int ablation, hipStream_t s);
 

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
     auto touch = [&](const char* line) {                     // line: wave-uniform address of row 0's 128-B line
         uint32_t o = toff;
         asm volatile("" : "+v"(o));
+        if (debug & 2) line = A;                               // tuning aid: touch a fixed line (no prefetch effect)
         __builtin_amdgcn_global_load_lds(VR_GLOBAL(uniform_ptr(line) + o), VR_LDS(dump), 4, 0, 0);
     };
     int sp = 0;
