@@ -51,3 +51,22 @@ def test_prepare_item_gpu_equals_host():
     assert g.input_ids == h.input_ids and g.image_bound == h.image_bound and len(dev) == len(h.slices)
     for a, b in zip(h.slices, dev):
         assert np.array_equal(a, b.cpu().numpy())
+
+
+def test_model_embeddings_do_not_depend_on_where_the_page_was_resized():
+    """DRModelForInference(gpu_preprocess=True) == (gpu_preprocess=False): same slices bit for
+    bit, hence the same embeddings bit for bit (sliced and unsliced pages in one batch)."""
+    from PIL import Image
+    from visrag_amd.modeling import DRModelForInference
+    from visrag_amd.synth import iter_synth_weights
+    cfg = tiny_config()
+    tok = StandInTokenizer(cfg.vocab_size)
+    m = DRModelForInference.build(cfg=cfg, state_dict=iter_synth_weights(cfg, 0, device="cuda"), max_images=16)
+    rng = np.random.default_rng(2)
+    imgs = [Image.fromarray(rng.integers(0, 256, size=hw + (3,), dtype=np.uint8)) for hw in [(112, 112), (200, 300), (90, 400)]]
+    batch = {"text": ["", "a caption", ""], "image": imgs}
+    m.gpu_preprocess = True
+    a = m(passage=batch, tokenizer=tok).p_reps.cpu().numpy()
+    m.gpu_preprocess = False
+    b = m(passage=batch, tokenizer=tok).p_reps.cpu().numpy()
+    assert np.array_equal(a, b)

@@ -111,6 +111,8 @@ class HipEncoder:
                     r[:n] = seq[i] + b0 + np.arange(n, dtype=np.int32)
                 rows.append(r)
         n_slices = len(slices)
+        if device_slices is None and n_slices and all(isinstance(t, torch.Tensor) and t.is_cuda for t in slices):
+            device_slices = slices            # items prepared on the GPU (gpu_resize.prepare_item_gpu)
         on_dev = 0
         keep = []
         if n_slices:

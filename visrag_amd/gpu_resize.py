@@ -59,8 +59,8 @@ def slice_image_gpu(img, cfg, device: int = 0):
 
 
 def prepare_item_gpu(text: str, image, tokenizer, cfg, max_inp_length: Optional[int] = 2048, device: int = 0):
-    """GPU-preprocessing twin of preprocess.prepare_item: returns (PreparedItem with placeholder
-    slices, list of device slices)."""
+    """GPU-preprocessing twin of preprocess.prepare_item: returns (PreparedItem whose slices are
+    uint8 cuda tensors, the same list of device slices)."""
     from .preprocess import prepare_item
     dev_slices: List[torch.Tensor] = []
     if image is None:
@@ -70,5 +70,5 @@ def prepare_item_gpu(text: str, image, tokenizer, cfg, max_inp_length: Optional[
     if grid is not None:
         ph += get_grid_placeholder(tokenizer, grid, cfg.query_num)
     it = prepare_item(ph + "\n" + text, None, tokenizer, cfg, max_inp_length)
-    it.slices = [None] * len(dev_slices)
+    it.slices = list(dev_slices)        # device tensors: HipEncoder.encode_items passes them on as they are
     return it, dev_slices

@@ -37,13 +37,15 @@ class DRModelForInference:
     """HIP-backed equivalent of openmatch's DRModelForInference for VisRAG-Ret."""
 
     def __init__(self, cfg: VisRAGRetConfig, encoder: HipEncoder, pooling: str = "wmean",
-                 normalize: bool = True):
+                 normalize: bool = True, gpu_preprocess: bool = True):
         if pooling != "wmean":
             raise ValueError("Unknown pooling type: {} (the HIP path fuses 'wmean')".format(pooling))
         assert normalize == True, "Normalize must be true"   # dense_retrieval_model.py:222
         self.cfg, self.encoder = cfg, encoder
         self.pooling, self.normalize = pooling, normalize
         self.micro_batch = encoder.max_seqs
+        # page resize + slicing on the GPU (bit-identical to PIL, gpu_resize.py) instead of on the host
+        self.gpu_preprocess = gpu_preprocess
 
     # ---- construction -----------------------------------------------------------------------
     @classmethod
@@ -80,7 +82,12 @@ class DRModelForInference:
         if tokenizer is None:
             raise ValueError("tokenizer is required (model(passage=batch, tokenizer=tok, ...))")
         texts, images = list(items["text"]), list(items.get("image", [None] * len(items["text"])))
-        prepared = prepare_batch(texts, images, tokenizer, self.cfg, max_inp_length)
+        if self.gpu_preprocess and any(im is not None for im in images):
+            from .gpu_resize import prepare_item_gpu
+            prepared = [prepare_item_gpu(t, im, tokenizer, self.cfg, max_inp_length, self.encoder.device)[0]
+                        for t, im in zip(texts, images)]
+        else:
+            prepared = prepare_batch(texts, images, tokenizer, self.cfg, max_inp_length)
         return None, self.encode_prepared(prepared)
 
     def encode_prepared(self, prepared: List[PreparedItem]) -> torch.Tensor:
