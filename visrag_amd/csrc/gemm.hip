@@ -39,6 +39,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     if constexpr (EPI == EPI_RESID) {
         if (!p.rowmap) { gemm_epilogue_resid_tile<4, 4, 4>(acc, p, m0 + wm * 64 + (lane & 15), n0 + wn * 64, lane >> 4); return; }
     }
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
+        // coalesced stores through the idle LDS stages (the main loop ends with a barrier): 8 KiB per wave
+        if ((p.N & 7) == 0 && (p.ldo & 7) == 0 && !p.direct_store) {
+            gemm_epilogue_tile_lds<EPI, 4>(acc, p, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * 8192);
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         gemm_epilogue_row<EPI>(acc[i], p, m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64, lane >> 4);
@@ -74,6 +81,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     const int wm = wave >> 2, wn = wave & 3;
     if constexpr (EPI == EPI_RESID) {
         if (!p.rowmap) { gemm_epilogue_resid_tile<8, 4, 4>(acc, p, m0 + wm * 128 + (lane & 15), n0 + wn * 64, lane >> 4); return; }
+    }
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
+        // (every main loop ends with a workgroup barrier: the stages are free, 16 KiB per wave)
+        if ((p.N & 7) == 0 && (p.ldo & 7) == 0 && !p.direct_store) {
+            gemm_epilogue_tile_lds<EPI, 8>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * 16384);
+            return;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -124,14 +138,17 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
+hipError_t launch_gemm(const GemmArgs& a_in, int epi, int variant, hipStream_t s) {
+    if (a_in.M <= 0) return hipSuccess;
+    static const int env_direct = getenv("VR_EPI_DIRECT") ? atoi(getenv("VR_EPI_DIRECT")) : 0;   // tuning aid
+    GemmArgs a = a_in;
+    if (env_direct) a.direct_store = 1;
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_32) return launch_gemm32(a, epi, s);
     if (variant == GEMM_VARIANT_256P) return launch_gemm256p(a, epi, s);
     if (variant == GEMM_VARIANT_256T) return launch_gemm256t(a, epi, s);
     if (variant == GEMM_VARIANT_256W4) return launch_gemm256w4(a, epi, s);
-    if (variant >= 20 && variant <= 26) return launch_gemm_ablate(a, variant, s);
+    if (variant >= 20 && variant <= 29) return launch_gemm_ablate(a, variant, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel
         if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID)

@@ -153,3 +153,98 @@ __device__ __forceinline__ void gemm_epilogue_resid_tile(f32x4 (&acc)[MI][NF], c
 }
 
 }  // namespace vr
+
+namespace vr {
+
+// bf16-output epilogues of a whole wave tile (MI x 16 rows, 64 accumulator columns) with
+// COALESCED stores.  In the MFMA C layout a lane owns 4 consecutive columns of one row, so a
+// direct store instruction writes 16 rows x 32 B — sixteen partial-line requests per instruction;
+// on the K = 1152 GEMMs the stores of the 256 x 256 tile cost ~11 us of a ~40 us tile (ablation:
+// the same kernel without its stores runs at 1.84 instead of 1.18 PFLOP/s).  Here the wave first
+// parks its converted tile in its private slice of the (now idle) LDS stages, swizzled like the
+// operand tiles, and reads it back row-wise: one store instruction = 8 rows x 128 B, full lines.
+//   wl: this wave's LDS slice, MI * 2 KiB (row pitch 128 B = 64 bf16; SwiGLU rows hold 32).
+template <int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], const GemmArgs& p, int mrow0, int nb,
+                                                       int lane, char* wl) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE, "bf16 outputs only");
+    const int fr = lane & 15, fq = lane >> 4;
+    // ---- 1. fused math in registers, bf16 tile into LDS
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = i * 16 + fr;
+        const int m = min(mrow0 + row, p.M - 1);               // (rows >= M are never stored)
+        char* lrow = wl + row * 128;
+        if constexpr (EPI == EPI_SWIGLU) {
+            // fragment j even = gate, j odd = up for the same 16 output columns (see gemm_epilogue_row)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r]);
+                const int c = jj * 2 + (fq >> 1);              // 16-byte chunk of the 64-byte output row
+                *reinterpret_cast<bf16x4*>(lrow + ((c ^ (row & 3)) << 4) + (fq & 1) * 8) = o;
+            }
+        } else {
+            if constexpr (EPI == EPI_ROPE) {
+                if (nb < p.rope_cols && nb < p.N) {
+                    const float* tab = p.rope_table + (size_t)p.rope_pos[m] * 64;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(tab + j * 16 + fq * 4);
+                        const f32x4 sn = *reinterpret_cast<const f32x4*>(tab + 32 + j * 16 + fq * 4);
+                        const f32x4 x1 = acc[i][j], x2 = acc[i][j + 2];
+                        acc[i][j] = x1 * cs - x2 * sn;
+                        acc[i][j + 2] = x2 * cs + x1 * sn;
+                    }
+                }
+            }
+            const float* rb = nullptr;
+            if constexpr (EPI != EPI_ROPE) {
+                if (p.rowbias) rb = p.rowbias + (size_t)(m % p.rowbias_period) * p.rowbias_ld;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = min(nb + j * 16 + fq * 4, p.N - 4);
+                f32x4 v = acc[i][j];
+                if constexpr (EPI != EPI_ROPE) {
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(EPI == EPI_GELU ? gelu_erf(v[r]) : v[r]);
+                const int c = j * 2 + (fq >> 1);               // 16-byte chunk of the 128-byte row
+                *reinterpret_cast<bf16x4*>(lrow + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+            }
+        }
+    }
+    // ---- 2. row-wise read-back (same wave: LDS operations of a wave execute in order), full-line stores
+    bf16_t* out = (bf16_t*)p.out;
+    if constexpr (EPI == EPI_SWIGLU) {
+        // 64-byte output rows: 4 lanes per row, 16 rows per instruction
+#pragma unroll
+        for (int it = 0; it < MI; ++it) {
+            const int row = it * 16 + (lane >> 2), c = lane & 3;
+            const u32x4 d = *reinterpret_cast<const u32x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4));
+            const int m = mrow0 + row, n = nb / 2 + c * 8;
+            if (m < p.M && 2 * n < p.N) {
+                const int orow = p.rowmap ? p.rowmap[m] : m;
+                if (orow >= 0) *reinterpret_cast<u32x4*>(out + (size_t)orow * p.ldo + n) = d;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < MI * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), c = lane & 7;
+            const u32x4 d = *reinterpret_cast<const u32x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4));
+            const int m = mrow0 + row, n = nb + c * 8;
+            if (m < p.M && n < p.N) {
+                const int orow = p.rowmap ? p.rowmap[m] : m;
+                if (orow >= 0) *reinterpret_cast<u32x4*>(out + (size_t)orow * p.ldo + n) = d;
+            }
+        }
+    }
+}
+
+}  // namespace vr

@@ -26,6 +26,7 @@ struct GemmArgs {
     const float* rope_table;         // f32 [max_pos][64] = cos[32] | sin[32]
     int rope_cols;                   // columns < rope_cols are rotated (q and k), rest copied (v)
     int raster_gm;                   // 256-tile kernels: m-tiles per raster group (0 = choose by W size)
+    int direct_store;                // tuning aid (VR_EPI_DIRECT=1): skip the LDS-staged coalesced epilogue
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // 256x192 tile (gemm192.hip): N % 192 == 0, epilogues BF16 / GELU / F32 / RESID only
