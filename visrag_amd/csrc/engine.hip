@@ -125,7 +125,7 @@ struct vr_model_s {
     // workspace
     int64_t Mcap = 0, Tcap = 0, Rcap = 0;     // padded rows: patches, tokens, resampler rows
     DevBuf w_im2col, w_hvit, w_xn, w_qkv, w_att, w_mlp, w_kv32, w_xkv, w_KV, w_ratt, w_rout, w_rln;
-    DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact;
+    DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact, w_part;   // w_part: split-K partial products [3][T][E] f32
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
     std::map<std::string, Tap> taps;
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
@@ -236,7 +236,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     if (m->arena) (void)hipHostFree(m->arena);
     if (m->arena_ev) (void)hipEventDestroy(m->arena_ev);
     for (DevBuf* b : {&m->r_q, &m->embed, &m->rope, &m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
-                      &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_dqkv,
+                      &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
                       &m->w_pix, &m->w_out})
         b->free();
@@ -509,6 +509,8 @@ static void resample_pos_host(const std::vector<float>& pe, int gi, int D, int g
         }
 }
 
+constexpr int DEC_KSPLIT_MAX = 3;   // decoder o / down projections: split-K factor when the tile grid is small
+
 static GemmArgs gemm_args(const void* A, int lda, const Linear& L, int M, void* out, int ldo) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = L.w.p; a.ldw = L.k_pad; a.M = M; a.N = L.n_pad; a.K = L.k_pad;
@@ -538,6 +540,7 @@ static int alloc_workspace(vr_model_s* m) {
     VRCHK(m->w_rln.alloc((size_t)R * E * 2));
     VRCHK(m->w_h.alloc((size_t)T * E * 4));
     VRCHK(m->w_dxn.alloc((size_t)T * E * 2));
+    VRCHK(m->w_part.alloc((size_t)DEC_KSPLIT_MAX * T * E * 4));
     VRCHK(m->w_dqkv.alloc((size_t)T * 3 * E * 2));
     VRCHK(m->w_datt.alloc((size_t)T * E * 2));
     VRCHK(m->w_dact.alloc((size_t)T * m->Ip * 2));
@@ -905,9 +908,47 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
     for (int i = 0; i < B; ++i) max_len = std::max(max_len, seq_offsets[i + 1] - seq_offsets[i]);
     if (max_len > m->rope_len) return fail(VR_ERR_CAPACITY, "sequence of %d tokens exceeds the RoPE table", max_len);
     VRCHK(prof_begin(m, VR_PROF_DECODER, s));
+    // o / down projections (N = E): with few rows the 256^2 grid is far smaller than the chip
+    // (T = 2176: 81 tiles on 256 CUs; the 128^2 grid of 306 tiles runs 1.2 waves at 550-700 TF).
+    // Split K over `ks` workgroups per tile instead (243 workgroups); the fp32 partial products are
+    // summed, in a fixed order, by the RMSNorm that follows anyway (launch_rmsnorm_accum), which also
+    // applies the scaled residual update — no reduction pass, no atomics, deterministic.
+    int ks = 1;
+    {
+        const long tiles = (long)((T + 255) / 256) * ((E + 255) / 256);
+        for (int cand = DEC_KSPLIT_MAX; cand > 1; --cand)
+            if (tiles * cand <= 256 && E % (cand * 64) == 0 && m->Ip % (cand * 64) == 0) { ks = cand; break; }
+        if (m->taps_on) ks = 1;          // (taps read h between the projection and the next norm)
+        static const int env_ks = getenv("VR_DEC_KSPLIT") ? atoi(getenv("VR_DEC_KSPLIT")) : -1;   // tuning aid
+        if (env_ks >= 1 && env_ks <= DEC_KSPLIT_MAX && E % (env_ks * 64) == 0 && m->Ip % (env_ks * 64) == 0 && !m->taps_on) ks = env_ks;
+    }
+    const size_t pstride = (size_t)T * E;
+    float* part = m->w_part.as<float>();
+    bool pend = false;                   // h still lacks residual_scale * sum(partials)
+    auto proj = [&](const void* A, int lda, const Linear& L) -> int {
+        if (ks > 1) {
+            GemmArgs a = gemm_args(A, lda, L, T, part, E);
+            a.ksplit = ks; a.split_stride = pstride;
+            HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256IL, s));
+            pend = true;
+        } else {
+            GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;
+            HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
+        }
+        return VR_OK;
+    };
+    auto norm = [&](const float* w) -> int {
+        if (pend) {
+            HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, ks, pstride, E, c.residual_scale, w, c.rms_norm_eps, m->w_dxn.p, E, s));
+            pend = false;
+        } else {
+            HIPCHK(launch_rmsnorm(h, T, E, E, w, c.rms_norm_eps, m->w_dxn.p, E, s));
+        }
+        return VR_OK;
+    };
     for (int l = 0; l < c.num_layers; ++l) {
         const DecLayer& L = m->layers[l];
-        HIPCHK(launch_rmsnorm(h, T, E, E, L.ln1.v.as<float>(), c.rms_norm_eps, m->w_dxn.p, E, s));
+        VRCHK(norm(L.ln1.v.as<float>()));
         {
             GemmArgs a = gemm_args(m->w_dxn.p, E, L.qkv, T, m->w_dqkv.p, 3 * E);
             a.rope_pos = m->w_pos.as<int>(); a.rope_table = m->rope.as<float>(); a.rope_cols = 2 * E;
@@ -921,11 +962,15 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
             a.max_q = max_len; a.causal = 1; a.q_shared = 0; a.scale = 1.0f / sqrtf(64.0f);
             HIPCHK(launch_attention(a, s));
         }
-        { GemmArgs a = gemm_args(m->w_datt.p, E, L.o, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
-        HIPCHK(launch_rmsnorm(h, T, E, E, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_dxn.p, E, s));
+        VRCHK(proj(m->w_datt.p, E, L.o));
+        VRCHK(norm(L.ln2.v.as<float>()));
         { GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
-        { GemmArgs a = gemm_args(m->w_dact.p, m->Ip, L.down, T, h, E); a.resid = h; a.alpha = c.residual_scale; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
+        VRCHK(proj(m->w_dact.p, m->Ip, L.down));
         if (l == 0) VRCHK(tap_store(m, "dec_layer0", h, T, E, E, false, s));
+    }
+    if (pend) {                          // last down projection: residual update only
+        HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, ks, pstride, E, c.residual_scale, nullptr, c.rms_norm_eps, nullptr, 0, s));
+        pend = false;
     }
     {
         double fl = 0;

@@ -58,7 +58,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = (p.N + G256_BN - 1) / G256_BN;
     const int tiles_m = (p.M + G256_BM - 1) / G256_BM;
-    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // split-K (EPI_F32 only): ksplit workgroups per tile, split s takes K-range [s, s+1) * K/ksplit and
+    // writes its partial product to out + s * split_stride; the consumer sums them in a fixed order
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int tt = xcd_remap(blockIdx.x, tiles_m * tiles_n * ks);
+    const int split = tt / (tiles_m * tiles_n);
+    const int t = tt - split * (tiles_m * tiles_n);
     // Grouped rasterisation: the ~32 tiles an XCD runs concurrently (consecutive t) form a patch of
     // GM m-tiles x 4 n-tiles, so every A / W k-slice fetched into that XCD's L2 is reused by 4 / GM
     // workgroups (row-major order would make it 1 A + 32 W slices per step: ~half the requests miss).
@@ -71,11 +76,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
 
     gemm256_acc_t acc;
     gemm256_zero(acc);
-    if constexpr (MODE == 4) gemm256_mainloop_il(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
-    else if constexpr (MODE == 1) gemm256_mainloop_p4(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
-    else if constexpr (MODE == 3) gemm256_mainloop_stag(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
-    else if constexpr (MODE == 2) gemm256_mainloop_mid(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
-    else gemm256_mainloop(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
+    const int Ks = p.K / ks;
+    const bf16_t* Ap = (const bf16_t*)p.A + (size_t)split * Ks;
+    const bf16_t* Wp = (const bf16_t*)p.W + (size_t)split * Ks;
+    if constexpr (MODE == 4) gemm256_mainloop_il(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else if constexpr (MODE == 1) gemm256_mainloop_p4(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else if constexpr (MODE == 3) gemm256_mainloop_stag(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else if constexpr (MODE == 2) gemm256_mainloop_mid(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else gemm256_mainloop(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+
+    if constexpr (EPI == EPI_F32) {
+        if (ks > 1) {
+            GemmArgs ps = p;
+            ps.out = (float*)p.out + (size_t)split * p.split_stride;
+            if (split > 0) ps.bias = nullptr;
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                gemm_epilogue_row<EPI_F32>(acc[i], ps, m0 + (wave >> 2) * 128 + i * 16 + (lane & 15), n0 + (wave & 3) * 64, lane >> 4);
+            return;
+        }
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -115,9 +136,15 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
                             : gemm256_bf16_kernel<EPI, 4>;
         static bool attr[5] = {false, false, false, false, false};
         if (!attr[vi]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr[vi] = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), G256_SMEM_BYTES, s, a);
+        int grid = tiles;
+        if (a.ksplit > 1) {
+            if (EPI != EPI_F32 || a.K % (a.ksplit * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
+            grid *= a.ksplit;
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), G256_SMEM_BYTES, s, a);
         return hipGetLastError();
     }
+    if (a.ksplit > 1) return hipErrorInvalidValue;          // split-K exists on the 256-tile kernels only
     const int tiles = (a.N / GEMM_BN) * ((a.M + GEMM_BM - 1) / GEMM_BM);
     GemmArgs a2 = a_in;
     if (a2.raster_gm <= 0) {

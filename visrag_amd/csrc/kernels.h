@@ -27,6 +27,8 @@ struct GemmArgs {
     int rope_cols;                   // columns < rope_cols are rotated (q and k), rest copied (v)
     int raster_gm;                   // 256-tile kernels: m-tiles per raster group (0 = choose by W size)
     int direct_store;                // tuning aid (VR_EPI_DIRECT=1): skip the LDS-staged coalesced epilogue
+    int ksplit;                      // 256-tile kernels, EPI_F32 only: split K over ksplit workgroups per tile;
+    size_t split_stride;             //   split s writes its partial product to out + s * split_stride (elements)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // 256x192 tile (gemm192.hip): N % 192 == 0, epilogues BF16 / GELU / F32 / RESID only
@@ -44,6 +46,11 @@ hipError_t launch_gemm_ablate(const GemmArgs& a, int ablation, hipStream_t s);
 // x f32 [rows][ldx] (dim used) -> bf16 [rows][ldo]; columns [dim, ldo) are written as zero.
 hipError_t launch_layernorm(const float* x, int rows, int dim, int ldx, const float* w, const float* b,
                             float eps, void* out, int ldo, hipStream_t s);
+// x += alpha * sum_s partial[s] (fp32, fixed order: deterministic), written back; then RMSNorm -> out
+// (out == null: accumulate only).  Closes a split-K GEMM (GemmArgs::ksplit) without a reduction pass.
+hipError_t launch_rmsnorm_accum(float* x, int rows, int dim, int ldx, const float* partial, int nsplit,
+                                size_t split_stride, int ldp, float alpha, const float* w, float eps, void* out,
+                                int ldo, hipStream_t s);
 hipError_t launch_rmsnorm(const float* x, int rows, int dim, int ldx, const float* w, float eps,
                           void* out, int ldo, hipStream_t s);
 

@@ -83,4 +83,63 @@ hipError_t launch_rmsnorm(const float* x, int rows, int dim, int ldx, const floa
     return hipGetLastError();
 }
 
+// Residual update fused into the RMSNorm that follows it: x <- x + alpha * (partial[0] + partial[1]
+// + ...), the split-K partial products of the o / down projections (fp32, summed in a fixed
+// order), then the usual RMSNorm of the new x.  One wave per row, the row stays in registers.
+__global__ __launch_bounds__(256) void rmsnorm_accum_kernel(float* __restrict__ x, int rows, int dim, int ldx,
+                                                            const float* __restrict__ partial, int nsplit,
+                                                            size_t split_stride, int ldp, float alpha,
+                                                            const float* __restrict__ w, float eps,
+                                                            bf16_t* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = dim >> 2;
+    f32x4* xr = reinterpret_cast<f32x4*>(x + (size_t)row * ldx);
+    f32x4 v[NORM_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            f32x4 acc = reinterpret_cast<const f32x4*>(partial + (size_t)row * ldp)[c];
+            for (int sp = 1; sp < nsplit; ++sp)
+                acc += reinterpret_cast<const f32x4*>(partial + sp * split_stride + (size_t)row * ldp)[c];
+            v[i] = xr[c] + alpha * acc;
+            xr[c] = v[i];
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+    if (!out) return;
+    s = wave_sum(s);
+    const float rstd = rsqrtf(s / dim + eps);
+    bf16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 y = v[i] * rstd * reinterpret_cast<const f32x4*>(w)[c];
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(y[r]);
+            reinterpret_cast<bf16x4*>(orow)[c] = o;
+        } else if (c * 4 < ldo) {
+            reinterpret_cast<bf16x4*>(orow)[c] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        }
+    }
+}
+
+hipError_t launch_rmsnorm_accum(float* x, int rows, int dim, int ldx, const float* partial, int nsplit,
+                                size_t split_stride, int ldp, float alpha, const float* w, float eps, void* out,
+                                int ldo, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (dim % 4 || ldx % 4 || ldp % 4 || dim > 64 * 4 * NORM_MAXV || dim > ldx || dim > ldp || nsplit < 1) return hipErrorInvalidValue;
+    if (out && (ldo % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rmsnorm_accum_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, partial, nsplit,
+                       split_stride, ldp, alpha, w, eps, (bf16_t*)out, ldo);
+    return hipGetLastError();
+}
+
 }  // namespace vr
