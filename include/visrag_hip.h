@@ -149,7 +149,8 @@ int vr_index_size(vr_index_t ix, int64_t* n);
  * sweep selects candidates, the survivors are re-scored in fp32).
  *   queries [nq][dim] float32;  out_scores [nq][k] float32;  out_ids [nq][k] int64
  * (all host or all device per `on_device`).  If the index holds fewer than k rows the
- * tail is filled with score -inf, id -1. */
+ * tail is filled with score -inf, id -1.  k = 1..1000: up to 26 on the fused sweep (the
+ * throughput path; --retrieve_depth 10 in eval.sh), deeper runs on GEMM + radix select. */
 int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k,
                     float* out_scores, int64_t* out_ids, int32_t on_device, void* stream);
 /* Merge per-shard results (e.g. after an RCCL all-gather): in [n_parts][nq][k] scores and

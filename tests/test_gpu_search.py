@@ -123,13 +123,43 @@ def test_search_device_tensors_and_sortedness():
     assert torch.equal(ri, ids[:64]) or (rv - sc[:64]).abs().max() < 1e-6
 
 
-def test_topk_merge_matches_host_rule():
-    P, nq, k = 4, 33, 10
+@pytest.mark.parametrize("nd,nq,dim,k", [(5000, 37, 256, 27), (20000, 300, 512, 100), (700, 5, 64, 1000),
+                                          (100000, 64, 2304, 100), (3000, 260, 128, 64)])
+def test_deep_retrieval_matches_oracle(nd, nq, dim, k):
+    """k > 26 (TREC-depth retrieval): GEMM + radix select + exact re-score path."""
+    C, Q = _unit(nd, dim, 11), _unit(nq, dim, 12)
+    ix = HipIndex(dim, nd)
+    ix.add(C)
+    sc, ids = ix.search(Q, k)
+    rs, ri = O.search_topk(Q, C, k)
+    kk = min(k, nd)
+    np.testing.assert_allclose(sc[:, :kk], rs, atol=1e-5, rtol=0)
+    for q, c in np.argwhere(ids[:, :kk] != ri):
+        j = int(np.flatnonzero(ri[q] == ids[q, c])[0]) if ids[q, c] in ri[q] else -1
+        assert j >= 0 and abs(rs[q, j] - rs[q, c]) < 3e-7, (q, c, ids[q, c], ri[q, c])
+    if kk < k:
+        assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()
+
+
+def test_deep_retrieval_ties():
+    """All rows identical: the k lowest ids, in order (ties at the selection threshold)."""
+    dim, nd, k = 64, 5000, 200
+    C = np.tile(_unit(1, dim, 6), (nd, 1))
+    Q = _unit(3, dim, 7)
+    ix = HipIndex(dim, nd); ix.add(C)
+    sc, ids = ix.search(Q, k)
+    assert np.array_equal(ids, np.tile(np.arange(k), (3, 1)))
+    with pytest.raises(Exception):
+        ix.search(Q, 1001)
+
+
+@pytest.mark.parametrize("P,nq,k", [(4, 33, 10), (8, 17, 100), (3, 5, 1000)])
+def test_topk_merge_matches_host_rule(P, nq, k):
     rng = np.random.default_rng(5)
     sc = np.sort(rng.standard_normal((P, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
     ids = rng.permutation(P * nq * k).reshape(P, nq, k).astype(np.int64)
     sc[1, :, 3] = sc[0, :, 2]                 # cross-part ties
-    ids[2, 5, 7:] = -1; sc[2, 5, 7:] = -np.inf
+    ids[2, nq // 2, 7:] = -1; sc[2, nq // 2, 7:] = -np.inf
     ms, mi = topk_merge(torch.from_numpy(sc).cuda(), torch.from_numpy(ids).cuda())
     hs, hi = merge_topk_host(sc, ids, k)
     assert np.array_equal(mi.cpu().numpy(), hi)

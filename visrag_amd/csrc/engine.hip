@@ -1014,8 +1014,8 @@ struct vr_index_s {
     int device = 0, dim = 0;
     int64_t cap = 0, n = 0;
     DevBuf f32, bf16;                 // [cap_pad][dim]
-    DevBuf q32, qbf, cs, ci, ck, os, oi, thr;  // query staging / candidates / outputs / thresholds
-    int64_t qcap = 0, ccap = 0, kcap = 0;
+    DevBuf q32, qbf, cs, ci, ck, os, oi, thr, sbuf;  // query staging / candidates / outputs / thresholds / big-k scores
+    int64_t qcap = 0, ccap = 0, kcap = 0, scap = 0;
 };
 
 extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_index_t* out) {
@@ -1037,7 +1037,7 @@ extern "C" int vr_index_destroy(vr_index_t ix) {
     if (!ix) return VR_OK;
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->ck, &ix->os, &ix->oi, &ix->thr}) b->free();
+    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->ck, &ix->os, &ix->oi, &ix->thr, &ix->sbuf}) b->free();
     delete ix;
     return VR_OK;
 }
@@ -1071,8 +1071,9 @@ extern "C" int vr_index_add(vr_index_t ix, const float* reps, int64_t n, int32_t
 extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k, float* out_scores,
                                int64_t* out_ids, int32_t on_device, void* stream) {
     if (!ix || !queries || !out_scores || !out_ids || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
-    const int kp = search_kprime(k);
-    if (kp == 0) return fail(VR_ERR_INVALID, "k=%d unsupported (1..26)", k);
+    const bool bigk = k > 26;             // deep retrieval: GEMM + radix select (search_bigk.hip)
+    if (k <= 0 || k > search_bigk_max()) return fail(VR_ERR_INVALID, "k=%d unsupported (1..%d)", k, search_bigk_max());
+    const int kp = bigk ? 0 : search_kprime(k);
     VRCHK(set_dev(ix->device));
     hipStream_t s = (hipStream_t)stream;
     const int dim = ix->dim;
@@ -1106,6 +1107,22 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
         SearchArgs a{};
         a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
         a.q_bf16 = ix->qbf.p; a.q_f32 = q32; a.nq = nq; a.k = k;
+        if (bigk) {
+            // score rows of <= 256 queries at a time: S[q][doc] = queries x index^T on the bf16 MFMA GEMM
+            constexpr int QB = 256;
+            const int64_t ldS = pad256l(ix->n);
+            if (ix->scap < QB * ldS) { VRCHK(ix->sbuf.alloc((size_t)QB * ldS * 4)); ix->scap = QB * ldS; }
+            a.out_scores = os; a.out_ids = oi;
+            for (int q0 = 0; q0 < nq; q0 += QB) {
+                const int nb = std::min(QB, nq - q0);
+                GemmArgs g{};
+                g.A = (const char*)ix->qbf.p + (size_t)q0 * dim * 2; g.lda = dim;
+                g.W = ix->bf16.p; g.ldw = dim; g.M = nb; g.N = (int)pad128l(ix->n); g.K = dim;
+                g.out = ix->sbuf.p; g.ldo = (int)ldS; g.alpha = 1.0f;
+                HIPCHK(launch_gemm(g, EPI_F32, GEMM_VARIANT_AUTO, s));
+                HIPCHK(launch_search_bigk(a, ix->sbuf.as<float>(), (size_t)ldS, q0, nb, s));
+            }
+        } else {
         a.n_chunks = search_num_chunks(ix->n, nq);
         a.thr_init = ix->thr.as<float>();
         const int64_t need = std::max<int64_t>(nqp * a.n_chunks * kp, nqp * search_prepass_floats());
@@ -1122,6 +1139,7 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
         }
         a.out_scores = os; a.out_ids = oi;
         HIPCHK(launch_search(a, s));
+        }
     }
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(out_scores, os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));

@@ -113,6 +113,11 @@ int search_prepass_floats();         // floats of cand_scores per (padded) query
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
 bool search_uses_256(int nq);         // more than 128 queries: main sweep on the 256^2 tile (search256.hip)
 hipError_t launch_sweep256(const SearchArgs& a, int kp, const float* thr, hipStream_t s);
+// k > 26 (search_bigk.hip): radix select over the block's score rows S + exact re-score; k <= search_bigk_max()
+int search_bigk_max();
+hipError_t launch_search_bigk(const SearchArgs& a, const float* S, size_t ldS, int q0, int nq_block, hipStream_t s);
+hipError_t launch_topk_merge_big(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
+                                 float* out_scores, int64_t* out_ids, hipStream_t s);   // n_parts * k <= 8192
 hipError_t launch_topk_merge(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t s);
 

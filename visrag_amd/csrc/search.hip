@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
 hipError_t launch_topk_merge(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
-    if (k > 64 || k <= 0) return hipErrorInvalidValue;
+    if (k <= 0) return hipErrorInvalidValue;
+    if (k > 64) return launch_topk_merge_big(scores, ids, n_parts, nq, k, out_scores, out_ids, s);
     hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, scores, ids, n_parts, nq, k,
                        out_scores, out_ids);
     return hipGetLastError();

@@ -66,7 +66,7 @@ def distributed_parallel_retrieve(args, topk: int, per_shard: bool = False) -> D
                 continue
             ix = HipIndex(dim, len(ids), dev)
             ix.add(reps)
-            sc, idx = ix.search(queries, min(topk, 26))
+            sc, idx = ix.search(queries, topk)
             ix.close()
             for qi, q in enumerate(qids):
                 for s, j in zip(sc[qi], idx[qi]):
