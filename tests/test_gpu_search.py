@@ -23,7 +23,8 @@ def _unit(n, d, seed):
 
 @pytest.mark.parametrize("nd,nq,dim,k", [(5000, 37, 256, 10), (130, 3, 64, 5), (20000, 300, 2304, 10),
                                           (1000, 130, 128, 20), (7, 2, 64, 10),
-                                          (3001, 257, 128, 26), (40037, 1000, 512, 10), (255, 129, 64, 3)])
+                                          (3001, 257, 128, 26), (40037, 1000, 512, 10), (255, 129, 64, 3),
+                                          (20000, 16, 512, 10), (3000, 1, 256, 26), (7, 2, 256, 10), (50001, 9, 2304, 10)])
 def test_search_matches_oracle(nd, nq, dim, k):
     C, Q = _unit(nd, dim, 1), _unit(nq, dim, 2)
     ix = HipIndex(dim, nd)
@@ -57,13 +58,14 @@ def test_search_ties_and_duplicates():
     assert list(ids[1, :2]) == [11, 900]
 
 
-@pytest.mark.parametrize("nq", [7, 200])
-def test_search_adversarial_orders(nq):
+@pytest.mark.parametrize("nq,dim", [(7, 64), (7, 256), (200, 64)])
+def test_search_adversarial_orders(nq, dim):
     """Corpora that defeat the threshold pre-pass: (a) every row identical (all scores tie: the
     lowest ids must win, every candidate list overflows), (b) scores increasing with the row id
     (each new row beats everything before it).  nq=200 runs the 256-tile sweep (wave-owned
-    half-lists + own compaction + the merge fallback), nq=7 the 128-tile one."""
-    dim, nd, k = 64, 20000, 10
+    half-lists + own compaction + the merge fallback), nq=7 the 128-tile sweep (dim 64) or the
+    streaming kernel (dim 256)."""
+    nd, k = 20000, 10
     rng = np.random.default_rng(5)
     v = _unit(1, dim, 9)[0]
     Q = v[None, :] + 0.02 * rng.standard_normal((nq, dim)).astype(np.float32)

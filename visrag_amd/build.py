@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvisrag_hip.so")
-SOURCES = ["gemm.hip", "gemm192.hip", "gemm32.hip", "gemm_ablate.hip", "gemm256p.hip", "gemm256t.hip", "gemm256w4.hip", "norm.hip", "attention.hip", "misc.hip", "search.hip", "search256.hip", "search_bigk.hip", "resize.hip", "pack.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemm192.hip", "gemm32.hip", "gemm_ablate.hip", "gemm256p.hip", "gemm256t.hip", "gemm256w4.hip", "norm.hip", "attention.hip", "misc.hip", "search.hip", "search256.hip", "search_small.hip", "search_bigk.hip", "resize.hip", "pack.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

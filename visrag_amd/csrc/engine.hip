@@ -1123,7 +1123,7 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
                 HIPCHK(launch_search_bigk(a, ix->sbuf.as<float>(), (size_t)ldS, q0, nb, s));
             }
         } else {
-        a.n_chunks = search_num_chunks(ix->n, nq);
+        a.n_chunks = search_uses_stream(nq, dim) ? search_stream_chunks() : search_num_chunks(ix->n, nq);
         a.thr_init = ix->thr.as<float>();
         const int64_t need = std::max<int64_t>(nqp * a.n_chunks * kp, nqp * search_prepass_floats());
         if (ix->ccap < need) {

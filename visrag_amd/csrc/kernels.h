@@ -111,6 +111,9 @@ int search_kprime(int k);            // candidates kept per (query, chunk); 0 if
 int search_num_chunks(int64_t n_docs, int nq);
 int search_prepass_floats();         // floats of cand_scores per (padded) query the threshold pre-pass needs
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
+bool search_uses_stream(int nq, int dim);   // nq <= 16: index streamed through registers (search_small.hip)
+int search_stream_chunks();
+hipError_t launch_search_stream(const SearchArgs& a, int kp, hipStream_t s);   // sweep only; merge: search_merge_wg_kernel
 bool search_uses_256(int nq);         // more than 128 queries: main sweep on the 256^2 tile (search256.hip)
 hipError_t launch_sweep256(const SearchArgs& a, int kp, const float* thr, hipStream_t s);
 // k > 26 (search_bigk.hip): radix select over the block's score rows S + exact re-score; k <= search_bigk_max()

@@ -240,6 +240,119 @@ __global__ __launch_bounds__(256) void search_merge_kernel(SearchArgs p) {
     rescore_emit<KP>(p, q, best, lane);
 }
 
+// ---- merge for FEW queries: one workgroup per query ------------------------------------------
+// With a handful of queries the wave-per-query merge above is a latency chain on a mostly idle
+// chip (512 chunk lists -> 77 us for one query).  Here 256 threads read all chunk entries with
+// independent loads, bound the KP-th best from the chunk heads, filter,
+// and the four waves re-score the KP candidates in parallel.
+template <int KP>
+__global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
+    __shared__ uint64_t lm[256];
+    __shared__ uint64_t surv[MERGE_CAP];
+    __shared__ uint64_t cand[64], exact_s[64];
+    __shared__ uint64_t thr_s;
+    __shared__ int n_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int total = p.n_chunks * KP;
+    const float* cs = p.cand_scores + (size_t)q * total;
+    const int* ci = p.cand_ids + (size_t)q * total;
+    // bound from the chunk HEADS (lists are sorted, so a head is its chunk's best): thread-local max
+    // over its chunks; the KP-th largest of the 64 folded maxima is <= KP distinct heads.  (Folding
+    // arbitrary entries instead mixes list positions and gives a far looser bound.)
+    uint64_t m = KEY_NONE;
+    for (int c = tid; c < p.n_chunks; c += 256) {
+        const int id = ci[c * KP];
+        const float sc = cs[c * KP];
+        const uint64_t key = id >= 0 ? make_key(sc, (uint32_t)id) : KEY_NONE;
+        m = key > m ? key : m;
+    }
+    lm[tid] = m;
+    if (tid < 64) exact_s[tid] = KEY_NONE;
+    __syncthreads();
+    if (wave == 0) {
+        uint64_t v = lm[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
+        const uint64_t t = shfl_u64(wave_sort_desc(v), KP - 1);
+        if (lane == 0) { thr_s = t; n_s = 0; }
+    }
+    __syncthreads();
+    const uint64_t thr = thr_s;
+    for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+        int id8[8];
+        float sc8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + 256 * u, total - 1);
+            id8[u] = (e0 + 256 * u < total) ? ci[e] : -1;
+            sc8[u] = cs[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (id8[u] >= 0) {
+                const uint64_t key = make_key(sc8[u], (uint32_t)id8[u]);
+                if (key >= thr) { const int pos = atomicAdd(&n_s, 1); if (pos < MERGE_CAP) surv[pos] = key; }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int n = n_s;
+        uint64_t best = KEY_NONE;
+        if (n <= MERGE_CAP) {
+            for (int base = 0; base < n; base += 64) {
+                const uint64_t key = (base + lane < n) ? surv[base + lane] : KEY_NONE;
+                best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+            }
+        } else {                                        // massive ties: merge everything
+            for (int base = 0; base < total; base += 64) {
+                const int e = base + lane;
+                uint64_t key = KEY_NONE;
+                if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
+                best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+            }
+        }
+        cand[lane] = best;
+    }
+    __syncthreads();
+    // exact fp32 re-scoring, one candidate per wave at a time (same summation order as rescore_emit)
+    const int nv = p.dim >> 2;
+    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
+    f32x4 qv[MERGE_MAXV];
+#pragma unroll
+    for (int i = 0; i < MERGE_MAXV; ++i) {
+        const int c = lane + i * 64;
+        qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = wave; c < KP; c += 4) {
+        const uint64_t key = cand[c];
+        if (key == KEY_NONE) continue;                  // wave-uniform
+        const uint32_t id = ~(uint32_t)key;
+        const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id * p.dim);
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < MERGE_MAXV; ++i) {
+            const int cc = lane + i * 64;
+            if (cc < nv) {
+                const f32x4 d = dr[cc];
+                a += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
+            }
+        }
+        a = wave_sum(a);
+        if (lane == 0) exact_s[c] = make_key(a, id);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const uint64_t ex = wave_sort_desc(exact_s[lane]);
+        if (lane < p.k) {
+            const bool ok = ex != KEY_NONE;
+            p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(ex >> 32)) : -INFINITY;
+            p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)ex) : (int64_t)-1;
+        }
+    }
+}
+
 int search_kprime(int k) {
     if (k <= 0) return 0;
     if (k <= 10) return 16;
@@ -272,6 +385,8 @@ int search_num_chunks(int64_t n_docs, int nq) {
     return chunks;
 }
 
+constexpr int SMALL_NQ = 16;        // up to here: no pre-pass, workgroup-per-query merge
+
 template <int KP>
 static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     const int q_tiles = (a.nq + 127) / 128;
@@ -281,7 +396,8 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEP_SMEM); attr = true; }
     hipError_t e;
     const float* thr = nullptr;
-    if (a.thr_init && n_tiles >= 8 * PRE_CHUNKS) {
+    // (a handful of queries: the chunks warm their thresholds up themselves — cheaper than two more launches)
+    if (a.thr_init && n_tiles >= 8 * PRE_CHUNKS && a.nq > SMALL_NQ) {
         static bool pattr = false;
         if (!pattr) { (void)hipFuncSetAttribute((const void*)search_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); pattr = true; }
         float* gmax = a.cand_scores;                   // [nq_pad128][PRE_CHUNKS][PRE_GROUPS], dead before the sweep writes
@@ -294,12 +410,15 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         thr = a.thr_init;
     }
     if (search_uses_256(a.nq)) return launch_sweep256(a, KP, thr, s);       // sweep + its own merge
-    {
+    if (search_uses_stream(a.nq, a.dim)) {
+        if ((e = launch_search_stream(a, KP, s)) != hipSuccess) return e;
+    } else {
         const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
         hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc, 1, thr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(search_merge_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    if (a.nq <= SMALL_NQ) hipLaunchKernelGGL(search_merge_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(search_merge_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
