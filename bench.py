@@ -162,6 +162,15 @@ def main():
     torch.cuda.synchronize()
     sweep_ms = e0.elapsed_time(e1) / args.search_steps
     search_flops = 2.0 * args.queries * len(index) * cfg.hidden_size
+    # the HBM-bound regime: ONE query against the local shard, bytes = bf16 index size
+    for _ in range(3):
+        index.search(Q[:1], args.topk)
+    e0.record()
+    for _ in range(20):
+        index.search(Q[:1], args.topk)
+    e1.record()
+    torch.cuda.synchronize()
+    one_ms = e0.elapsed_time(e1) / 20
 
     if rank != 0:
         if world > 1:
@@ -219,7 +228,10 @@ def main():
                    "local_sweep_tflops": round(search_flops / (sweep_ms * 1e-3) / 1e12, 1),
                    "local_sweep_frac_of_mfma_peak": round(search_flops / (sweep_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                    "index_GBps": round(len(index) * cfg.hidden_size * 2 / (sweep_ms * 1e-3) / 1e9, 1),
-                   "query_encode_per_sec": round(args.queries / q_encode_s, 1)},
+                   "query_encode_per_sec": round(args.queries / q_encode_s, 1),
+                   "single_query": {"ms": round(one_ms, 4), "bound": "hbm",
+                                    "index_GBps": round(len(index) * cfg.hidden_size * 2 / (one_ms * 1e-3) / 1e9, 1),
+                                    "frac_of_hbm_peak": round(len(index) * cfg.hidden_size * 2 / (one_ms * 1e-3) / 1e9 / 8000.0, 4)}},
         "roofline": roofline,
         "phases": phases,
     }
