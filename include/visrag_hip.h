@@ -91,6 +91,10 @@ int vr_model_load_weight(vr_model_t m, const char* name, const void* data,
 /* Check that every required weight arrived and build derived tables (packed / padded
  * bf16 weights, resampler query projection, RoPE table). */
 int vr_model_finalize(vr_model_t m);
+/* A second handle on the same (finalised) weights with its own workspace: lets a caller keep two
+ * batches in flight on two HIP streams (each vr_encode call is still ordered on the stream it is
+ * given).  `src` must outlive the clone; the clone is destroyed with vr_model_destroy. */
+int vr_model_clone(vr_model_t src, vr_model_t* out);
 
 /* Encode a batch of items (pages and/or text queries) to unit-norm embeddings.
  *   slices      n_slices pointers to uint8 HWC (RGB) images, all on host or all on device

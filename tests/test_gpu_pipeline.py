@@ -79,3 +79,31 @@ def test_encode_retrieve_trec_pipeline(tmp_path):
     assert e.shape == (2, cfg.hidden_size) and np.allclose(np.linalg.norm(e, axis=1), 1, atol=1e-5)
     e = encode(model, tok, ["a text query"])
     assert e.shape == (1, cfg.hidden_size)
+
+
+def test_two_batches_in_flight_give_the_same_embeddings():
+    """DRModelForInference(pipeline=2): consecutive calls rotate over two workspaces / streams that
+    share the weights (vr_model_clone); results are bit-identical to the single-stream model."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from visrag_amd.config import tiny_config
+    from visrag_amd.modeling import DRModelForInference
+    from visrag_amd.synth import iter_synth_weights
+    from visrag_amd.tokenizer import StandInTokenizer
+    cfg = tiny_config()
+    tok = StandInTokenizer(cfg.vocab_size)
+    m = DRModelForInference.build(cfg=cfg, state_dict=iter_synth_weights(cfg, 0, device="cuda"), max_images=16)
+    rng = np.random.default_rng(3)
+    batches = []
+    for b in range(5):
+        imgs = [Image.fromarray(rng.integers(0, 256, size=hw + (3,), dtype=np.uint8)) for hw in [(112, 112), (150 + 10 * b, 260)]]
+        batches.append({"text": ["", f"caption {b}"], "image": imgs})
+    ref = [m(passage=b, tokenizer=tok).p_reps.clone() for b in batches]
+    m.set_pipeline(2)
+    got = [m(passage=b, tokenizer=tok).p_reps for b in batches]      # no sync in between: two in flight
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    q = m(query={"text": ["what is shown"], "image": [None]}, tokenizer=tok).q_reps
+    assert q.shape == (1, cfg.hidden_size) and bool(torch.isfinite(q).all())

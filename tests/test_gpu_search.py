@@ -166,3 +166,19 @@ def test_topk_merge_matches_host_rule(P, nq, k):
     hs, hi = merge_topk_host(sc, ids, k)
     assert np.array_equal(mi.cpu().numpy(), hi)
     np.testing.assert_array_equal(ms.cpu().numpy(), hs)
+
+
+def test_search_on_a_side_stream():
+    """First add/search of a fresh index issued on a non-default (non-blocking) torch stream: the
+    library's buffers must be ready on THAT stream (allocation-time memsets run on the NULL stream)."""
+    C, Q = _unit(30000, 256, 21), _unit(300, 256, 22)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ix = HipIndex(256, 30000)
+        ix.add(torch.from_numpy(C).cuda())
+        sc, ids = ix.search(torch.from_numpy(Q).cuda(), 10)
+        sc1, ids1 = ix.search(torch.from_numpy(Q[:3]).cuda(), 10)
+    s.synchronize()
+    rs, ri = O.search_topk(Q, C, 10)
+    assert np.array_equal(ids.cpu().numpy(), ri) and np.array_equal(ids1.cpu().numpy(), ri[:3])
+    np.testing.assert_allclose(sc.cpu().numpy(), rs, atol=1e-5, rtol=0)

@@ -72,6 +72,10 @@ struct DevBuf {
         bytes = n;
         e = hipMemset(p, 0, n);
         if (e != hipSuccess) return fail(VR_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+        // the memset runs on the NULL stream; callers use the buffer on their own (possibly
+        // non-blocking) stream right away, which is not ordered after it: finish it here
+        e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) return fail(VR_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
         return VR_OK;
     }
     void free() {
@@ -104,6 +108,7 @@ struct vr_model_s {
     int device = 0;
     vr_config_t c{};
     bool finalized = false, taps_on = false;
+    bool borrowed = false;                    // vr_model_clone: weights belong to another handle
     // dims
     int D = 0, Dp = 0, F = 0, Fp = 0, E = 0, I = 0, Ip = 0, Kpe = 0, Kpe_p = 0, Q = 0;
     // weights
@@ -143,8 +148,7 @@ static int arena_begin(vr_model_s* m, size_t need) {
     if (m->arena_pending) { HIPCHK(hipEventSynchronize(m->arena_ev)); m->arena_pending = false; }
     if (!m->arena_ev) HIPCHK(hipEventCreateWithFlags(&m->arena_ev, hipEventDisableTiming));
     if (m->arena_cap < need) {
-        for (auto& pc : m->prof) for (hipEvent_t e : pc.ev) (void)hipEventDestroy(e);
-    if (m->arena) (void)hipHostFree(m->arena);
+        if (m->arena) (void)hipHostFree(m->arena);
         m->arena = nullptr; m->arena_cap = 0;
         const size_t cap = std::max(need, (size_t)4 << 20);
         HIPCHK(hipHostMalloc((void**)&m->arena, cap, hipHostMallocDefault));
@@ -226,16 +230,19 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     if (!m) return VR_OK;
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
-    auto fl = [](Linear& l) { l.w.free(); l.b.free(); };
-    fl(m->patch); fl(m->r_kvproj); fl(m->r_kv); fl(m->r_out); fl(m->r_proj);
-    for (auto& b : m->blocks) { fl(b.qkv); fl(b.proj); fl(b.fc1); fl(b.fc2); b.n1w.v.free(); b.n1b.v.free(); b.n2w.v.free(); b.n2b.v.free(); }
-    for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); l.ln1.v.free(); l.ln2.v.free(); }
-    for (Vec* v : {&m->vit_nw, &m->vit_nb, &m->r_lnq_w, &m->r_lnq_b, &m->r_lnkv_w, &m->r_lnkv_b, &m->r_lnpost_w, &m->r_lnpost_b, &m->final_norm}) v->v.free();
+    if (!m->borrowed) {
+        auto fl = [](Linear& l) { l.w.free(); l.b.free(); };
+        fl(m->patch); fl(m->r_kvproj); fl(m->r_kv); fl(m->r_out); fl(m->r_proj);
+        for (auto& b : m->blocks) { fl(b.qkv); fl(b.proj); fl(b.fc1); fl(b.fc2); b.n1w.v.free(); b.n1b.v.free(); b.n2w.v.free(); b.n2b.v.free(); }
+        for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); l.ln1.v.free(); l.ln2.v.free(); }
+        for (Vec* v : {&m->vit_nw, &m->vit_nb, &m->r_lnq_w, &m->r_lnq_b, &m->r_lnkv_w, &m->r_lnkv_b, &m->r_lnpost_w, &m->r_lnpost_b, &m->final_norm}) v->v.free();
+        for (DevBuf* b : {&m->r_q, &m->embed, &m->rope}) b->free();
+    }
     for (auto& g : m->grids) { g.second.vit_pos.free(); g.second.pos_k.free(); }
     for (auto& pc : m->prof) for (hipEvent_t e : pc.ev) (void)hipEventDestroy(e);
     if (m->arena) (void)hipHostFree(m->arena);
     if (m->arena_ev) (void)hipEventDestroy(m->arena_ev);
-    for (DevBuf* b : {&m->r_q, &m->embed, &m->rope, &m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
+    for (DevBuf* b : {&m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
                       &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
                       &m->w_pix, &m->w_out})
@@ -988,6 +995,32 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
     m->arena_pending = true;
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out_reps, dst, (size_t)B * E * 4, hipMemcpyDeviceToHost, s));
     if (!out_on_device || (n_slices > 0 && !slices_on_device)) HIPCHK(hipStreamSynchronize(s));   // host buffers consumed
+    return VR_OK;
+}
+
+// A second handle on the SAME weights with its own workspace, per-grid tables, pinned arena and
+// profiling state: two batches can then be in flight on two HIP streams (the tails and the
+// LayerNorm/epilogue phases of one batch's kernels overlap the other's GEMMs).  The source handle
+// must outlive its clones.
+extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
+    if (!src || !out) return fail(VR_ERR_INVALID, "src/out is NULL");
+    if (!src->finalized) return fail(VR_ERR_STATE, "vr_model_clone before vr_model_finalize");
+    VRCHK(set_dev(src->device));
+    vr_model_s* m = new vr_model_s(*src);          // shallow: the weight buffers are aliased, never freed by the clone
+    m->borrowed = true;
+    for (DevBuf* b : {&m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
+                      &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
+                      &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out}) {
+        b->p = nullptr; b->bytes = 0;
+    }
+    m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)
+    m->taps.clear(); m->taps_on = false;
+    m->prof_on = false;
+    for (auto& pc : m->prof) { pc.ev.clear(); pc.used = 0; pc.ms = 0; pc.flops = 0; pc.launches = 0; }
+    m->arena = nullptr; m->arena_cap = 0; m->arena_used = 0; m->arena_ev = nullptr; m->arena_pending = false;
+    const int r = alloc_workspace(m);
+    if (r != VR_OK) { (void)vr_model_destroy(m); return r; }
+    *out = m;
     return VR_OK;
 }
 

@@ -41,6 +41,21 @@ class HipEncoder:
         _lib.check(self.lib.vr_model_create(self.device, C.byref(self._c), C.byref(self._h)), "vr_model_create")
         self.finalized = False
 
+    def clone(self) -> "HipEncoder":
+        """A second encoder on the SAME device weights with its own workspace (vr_model_clone): run it on
+        another torch stream to keep two batches in flight.  Keeps a reference to its source."""
+        if not self.finalized:
+            raise RuntimeError("clone() needs a finalized encoder")
+        other = object.__new__(HipEncoder)
+        other.lib, other.cfg, other.device = self.lib, self.cfg, self.device
+        other.max_images, other.max_tokens, other.max_seqs = self.max_images, self.max_tokens, self.max_seqs
+        other._c = self._c
+        other._h = C.c_void_p()
+        other._src = self
+        _lib.check(self.lib.vr_model_clone(self._h, C.byref(other._h)), "vr_model_clone")
+        other.finalized = True
+        return other
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self.lib.vr_model_destroy(self._h)

@@ -44,6 +44,11 @@ class DRModelForInference:
         self.cfg, self.encoder = cfg, encoder
         self.pooling, self.normalize = pooling, normalize
         self.micro_batch = encoder.max_seqs
+        # batches in flight: slot j = its own HipEncoder (clone: same weights, own workspace) + HIP stream.
+        # Consecutive model(...) calls rotate over the slots, so batch i+1 (pre-processing included) runs
+        # while batch i is still on the GPU; the caller's stream waits for each result, never the reverse.
+        self._slots = [(encoder, None)]
+        self._rr = 0
         # page resize + slicing on the GPU (bit-identical to PIL, gpu_resize.py) instead of on the host
         self.gpu_preprocess = gpu_preprocess
 
@@ -51,7 +56,7 @@ class DRModelForInference:
     @classmethod
     def build(cls, model_args=None, cfg: Optional[VisRAGRetConfig] = None,
               state_dict: Optional[Iterable[Tuple[str, torch.Tensor]]] = None, device: int = 0,
-              max_images: int = 32, max_tokens: int = 4096, max_seqs: int = 64, **_):
+              max_images: int = 32, max_tokens: int = 4096, max_seqs: int = 64, pipeline: int = 1, **_):
         """`model_args` needs `.model_name_or_path` (a HF checkpoint dir with *.safetensors /
         pytorch_model*.bin and config.json) unless `state_dict` is given; `.pooling` and
         `.normalize` are honoured like the reference (arguments.py)."""
@@ -66,7 +71,18 @@ class DRModelForInference:
                 raise ValueError("need model_args.model_name_or_path or state_dict")
             state_dict = iter_checkpoint(path)
         enc.load_state_dict(state_dict)
-        return cls(cfg, enc, pooling=pooling, normalize=normalize)
+        model = cls(cfg, enc, pooling=pooling, normalize=normalize)
+        model.set_pipeline(pipeline)
+        return model
+
+    def set_pipeline(self, depth: int) -> None:
+        """depth >= 2: keep that many batches in flight (one workspace + stream each, weights shared)."""
+        depth = max(1, int(depth))
+        enc = self.encoder
+        dev = torch.device(f"cuda:{enc.device}")
+        self._slots = [(enc, None)] if depth == 1 else \
+            [(enc if j == 0 else enc.clone(), torch.cuda.Stream(device=dev)) for j in range(depth)]
+        self._rr = 0
 
     def eval(self):
         return self
@@ -82,17 +98,31 @@ class DRModelForInference:
         if tokenizer is None:
             raise ValueError("tokenizer is required (model(passage=batch, tokenizer=tok, ...))")
         texts, images = list(items["text"]), list(items.get("image", [None] * len(items["text"])))
-        if self.gpu_preprocess and any(im is not None for im in images):
-            from .gpu_resize import prepare_item_gpu
-            prepared = [prepare_item_gpu(t, im, tokenizer, self.cfg, max_inp_length, self.encoder.device)[0]
-                        for t, im in zip(texts, images)]
-        else:
-            prepared = prepare_batch(texts, images, tokenizer, self.cfg, max_inp_length)
-        return None, self.encode_prepared(prepared)
+        enc, side = self._slots[self._rr % len(self._slots)]
+        self._rr += 1
 
-    def encode_prepared(self, prepared: List[PreparedItem]) -> torch.Tensor:
+        def run():
+            if self.gpu_preprocess and any(im is not None for im in images):
+                from .gpu_resize import prepare_item_gpu
+                prepared = [prepare_item_gpu(t, im, tokenizer, self.cfg, max_inp_length, enc.device)[0]
+                            for t, im in zip(texts, images)]
+            else:
+                prepared = prepare_batch(texts, images, tokenizer, self.cfg, max_inp_length)
+            return self.encode_prepared(prepared, enc)
+
+        if side is None:
+            return None, run()
+        cur = torch.cuda.current_stream(side.device)
+        with torch.cuda.stream(side):          # resize kernels + encode of this batch: all on the slot's stream
+            reps = run()
+            done = side.record_event()
+        cur.wait_event(done)                   # consumers on the caller's stream are ordered after the batch
+        reps.record_stream(cur)
+        return None, reps
+
+    def encode_prepared(self, prepared: List[PreparedItem], enc: Optional[HipEncoder] = None) -> torch.Tensor:
         """Splits into micro-batches that fit the workspace (tokens / sequences)."""
-        enc = self.encoder
+        enc = enc or self.encoder
         outs, cur, tok = [], [], 0
         for it in prepared:
             n = len(it.input_ids)
