@@ -56,7 +56,7 @@ class DRModelForInference:
     @classmethod
     def build(cls, model_args=None, cfg: Optional[VisRAGRetConfig] = None,
               state_dict: Optional[Iterable[Tuple[str, torch.Tensor]]] = None, device: int = 0,
-              max_images: int = 32, max_tokens: int = 4096, max_seqs: int = 64, pipeline: int = 1, **_):
+              max_images: int = 32, max_tokens: int = 4096, max_seqs: int = 64, pipeline: int = 2, **_):
         """`model_args` needs `.model_name_or_path` (a HF checkpoint dir with *.safetensors /
         pytorch_model*.bin and config.json) unless `state_dict` is given; `.pooling` and
         `.normalize` are honoured like the reference (arguments.py)."""
