@@ -318,6 +318,118 @@ __global__ __launch_bounds__(256) void search_merge256_kernel(SearchArgs p) {
     rescore_emit<KP>(p, q, best, lane);
 }
 
+// One WORKGROUP per query (256 threads): thread = list (t, t + 256, ...), so all list walks of a
+// query run in parallel, and the four waves re-score the KP candidates concurrently.  With a few
+// hundred queries the wave-per-query merge above leaves most of the chip idle behind a chain of
+// dependent loads (128 queries: 101 us).
+template <int KP>
+__global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
+    __shared__ uint64_t lm[256];
+    __shared__ uint64_t surv[MERGE_CAP];
+    __shared__ uint64_t cand[64], exact_s[64];
+    __shared__ uint64_t thr_s;
+    __shared__ int n_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int lists = p.n_chunks * 2;
+    const int* cnts = p.cand_ids + (size_t)q * lists;
+    const unsigned long long* keys = p.cand_keys + (size_t)q * lists * HL_CAP;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+    uint64_t m = KEY_NONE;
+    for (int l = tid; l < lists; l += 256) {
+        const int c = cnts[l];
+        const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)l * HL_CAP);
+        for (int e = 0; e < c; e += 4) {
+            const u64x2 a = row[e >> 1], b2 = row[(e >> 1) + 1];
+            const uint64_t k0 = a[0], k1 = e + 1 < c ? a[1] : KEY_NONE;
+            const uint64_t k2 = e + 2 < c ? b2[0] : KEY_NONE, k3 = e + 3 < c ? b2[1] : KEY_NONE;
+            const uint64_t x = k0 > k1 ? k0 : k1, y = k2 > k3 ? k2 : k3;
+            const uint64_t z = x > y ? x : y;
+            m = z > m ? z : m;
+        }
+    }
+    lm[tid] = m;
+    if (tid < 64) exact_s[tid] = KEY_NONE;
+    __syncthreads();
+    if (wave == 0) {
+        uint64_t v = lm[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
+        const uint64_t t = shfl_u64(wave_sort_desc(v), KP - 1);
+        if (lane == 0) { thr_s = t; n_s = 0; }
+    }
+    __syncthreads();
+    const uint64_t thr = thr_s;
+    for (int l = tid; l < lists; l += 256) {
+        const int c = cnts[l];
+        const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)l * HL_CAP);
+        for (int e = 0; e < c; e += 2) {
+            const u64x2 a = row[e >> 1];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (e + u < c && a[u] >= thr && a[u] != KEY_NONE) {
+                    const int pos = atomicAdd(&n_s, 1);
+                    if (pos < MERGE_CAP) surv[pos] = a[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int n = n_s;
+        uint64_t best = KEY_NONE;
+        if (n <= MERGE_CAP) {
+            for (int base = 0; base < n; base += 64) {
+                const uint64_t key = (base + lane < n) ? surv[base + lane] : KEY_NONE;
+                best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+            }
+        } else {
+            for (int l = 0; l < lists; ++l) {
+                const int c = cnts[l];
+                const uint64_t key = (lane < c) ? keys[(size_t)l * HL_CAP + lane] : KEY_NONE;
+                best = (l == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+            }
+        }
+        cand[lane] = best;
+    }
+    __syncthreads();
+    const int nv = p.dim >> 2;
+    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
+    f32x4 qv[MERGE_MAXV];
+#pragma unroll
+    for (int i = 0; i < MERGE_MAXV; ++i) {
+        const int c = lane + i * 64;
+        qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = wave; c < KP; c += 4) {
+        const uint64_t key = cand[c];
+        if (key == KEY_NONE) continue;                  // wave-uniform
+        const uint32_t id = ~(uint32_t)key;
+        const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id * p.dim);
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < MERGE_MAXV; ++i) {
+            const int cc = lane + i * 64;
+            if (cc < nv) {
+                const f32x4 d = dr[cc];
+                a += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
+            }
+        }
+        a = wave_sum(a);
+        if (lane == 0) exact_s[c] = make_key(a, id);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const uint64_t ex = wave_sort_desc(exact_s[lane]);
+        if (lane < p.k) {
+            const bool ok = ex != KEY_NONE;
+            p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(ex >> 32)) : -INFINITY;
+            p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)ex) : (int64_t)-1;
+        }
+    }
+}
+
 template <int KP>
 static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s) {
     const int q_tiles = (a.nq + 255) / 256;
@@ -331,7 +443,10 @@ static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s)
     hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr, debug);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(search_merge256_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    static int wgm = -1;       // tuning aid: VR_MERGE256_WG = largest nq merged by one workgroup per query
+    if (wgm < 0) { const char* e2 = getenv("VR_MERGE256_WG"); wgm = e2 ? atoi(e2) : 1 << 30; }
+    if (a.nq <= wgm) hipLaunchKernelGGL(search_merge256_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(search_merge256_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
