@@ -1122,8 +1122,7 @@ extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, 
         HIPCHK(hipMemcpyAsync(ix->q32.p, queries, (size_t)nq * dim * 4, hipMemcpyHostToDevice, s));
         q32 = ix->q32.as<float>();
     }
-    HIPCHK(hipMemsetAsync(ix->qbf.p, 0, (size_t)nqp * dim * 2, s));
-    HIPCHK(launch_f32_to_bf16(q32, ix->qbf.p, (size_t)nq * dim, s));
+    HIPCHK(launch_f32_to_bf16_pad(q32, ix->qbf.p, (size_t)nq * dim, (size_t)nqp * dim, s));   // rows >= nq: zeros
     float* os = out_scores; int64_t* oi = out_ids;
     if (!on_device) {
         VRCHK(ix->os.alloc((size_t)nq * k * 4));

@@ -79,6 +79,7 @@ hipError_t launch_embed_gather(const int* ids, int T, const void* table, int dim
 hipError_t launch_pool(const float* h, const int* seq_offsets, int B, int dim, const float* norm_w,
                        float eps, float* out, float* tap_hidden, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
+hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s);   // + zero tail
 // split x (f32) into hi + lo bf16 parts (x ~= hi + lo to ~16 bits of mantissa)
 hipError_t launch_split_bf16(const float* in, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t launch_iota_pos(const int* seq_offsets, int B, int* pos, hipStream_t s);

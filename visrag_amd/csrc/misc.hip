@@ -164,6 +164,30 @@ hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t 
     return hipGetLastError();
 }
 
+// f32 -> bf16 of the first n elements, zeros up to n_total (query rows + their padding in one launch;
+// n and n_total multiples of 4)
+__global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n, size_t n_total) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i < n_total; i += stride) {
+        bf16x4 o = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if (i < n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+        }
+        *reinterpret_cast<bf16x4*>(out + i) = o;
+    }
+}
+
+hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s) {
+    if (n_total == 0) return hipSuccess;
+    if ((n | n_total) & 3) return hipErrorInvalidValue;
+    const int blocks = (int)min((size_t)2048, (n_total / 4 + 255) / 256);
+    hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(blocks), dim3(256), 0, s, in, (bf16_t*)out, n, n_total);
+    return hipGetLastError();
+}
+
 __global__ void split_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ hi,
                                   bf16_t* __restrict__ lo, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
