@@ -106,27 +106,48 @@ import os, sys
 sys.path.insert(0, os.environ["VR_ROOT"])
 import numpy as np, torch, torch.distributed as dist
 from oracle import visrag_ret_oracle as O
-from visrag_amd.retriever import merge_topk_host
+from visrag_amd.retriever import merge_topk_host, sharded_search
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["VR_PORT"],
                         rank=int(os.environ["VR_RANK"]), world_size=2)
 rank = dist.get_rank()
 rng = np.random.default_rng(0)
 C = rng.standard_normal((400, 16)).astype(np.float32); Q = rng.standard_normal((5, 16)).astype(np.float32)
+C[300] = C[20]                                          # exact tie across the two shards
 lo = rank * 200
-s, i = O.search_topk(Q, C[lo:lo + 200], 7)            # local shard search (CPU stand-in for HipIndex)
-ts, ti = torch.from_numpy(s.copy()), torch.from_numpy(i + lo)
-gs = [torch.empty_like(ts) for _ in range(2)]; gi = [torch.empty_like(ti) for _ in range(2)]
-dist.all_gather(gs, ts); dist.all_gather(gi, ti)       # the one exchange step of the path
-ms, mi = merge_topk_host(torch.stack(gs).numpy(), torch.stack(gi).numpy(), 7)
+calls = {"n": 0}
+real_gather = dist.all_gather_into_tensor
+def counting_gather(*a, **k):
+    calls["n"] += 1
+    return real_gather(*a, **k)
+dist.all_gather_into_tensor = counting_gather
+# the PRODUCT's multi-rank function; only the device pieces are swapped for CPU stand-ins:
+# HipIndex.search -> the oracle's matmul + top-k on this rank's shard, vr_topk_merge -> merge_topk_host
+def local_search(q, k):
+    return O.search_topk(q.numpy(), C[lo:lo + 200], k)
+def merge(all_sc, all_ids):
+    s, i = merge_topk_host(all_sc.numpy(), all_ids.numpy(), all_sc.shape[2])
+    return torch.from_numpy(s), torch.from_numpy(i)
+ms, mi = sharded_search(None, torch.from_numpy(Q), 7, id_offset=lo, local_search=local_search, merge=merge)
+assert calls["n"] == 1, calls                           # ONE exchange step
 rs, ri = O.search_topk(Q, C, 7)
-assert np.array_equal(mi, ri) and np.allclose(ms, rs), rank
+assert np.array_equal(mi.numpy(), ri) and np.array_equal(ms.numpy(), rs), rank
+# fewer rows than k on one rank: its tail (-inf, -1) must survive the packed exchange
+def short_search(q, k):                                 # (HipIndex pads a short shard with score -inf, id -1)
+    n = 3 if rank == 1 else 200
+    s, i = O.search_topk(q.numpy(), C[lo:lo + n], min(k, n))
+    pad = k - s.shape[1]
+    return (np.pad(s, ((0, 0), (0, pad)), constant_values=-np.inf), np.pad(i, ((0, 0), (0, pad)), constant_values=-1))
+ms, mi = sharded_search(None, torch.from_numpy(Q), 7, id_offset=lo, local_search=short_search, merge=merge)
+rs, ri = O.search_topk(Q, np.concatenate([C[:200], C[200:203]]), 7)
+assert np.array_equal(mi.numpy(), ri) and np.array_equal(ms.numpy(), rs), rank
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
 
 def test_sharded_retrieval_world2_gloo(tmp_path):
-    """world_size 2 on CPU (gloo): shard -> local top-k -> all_gather -> merge == global."""
+    """world_size 2 on CPU (gloo): the product's retriever.sharded_search (shard -> local top-k ->
+    ONE packed all_gather -> merge) == global search."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     script = tmp_path / "w.py"
@@ -136,7 +157,7 @@ def test_sharded_retrieval_world2_gloo(tmp_path):
         env = dict(os.environ, VR_ROOT=ROOT, VR_PORT=str(port), VR_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=120)[0] for p in procs]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
 
 

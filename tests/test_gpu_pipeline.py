@@ -48,8 +48,8 @@ def test_encode_retrieve_trec_pipeline(tmp_path):
     reps, ids = U.read_shard(os.path.join(tmp_path, [n for n in names if n.startswith("embeddings.corpus")][0]))
     assert reps.dtype == np.float32 and reps.shape[1] == cfg.hidden_size and len(ids) == len(reps)
 
-    run = distributed_parallel_retrieve(args, k)
-    union = distributed_parallel_retrieve(args, k, per_shard=True)      # reference semantics: k per shard
+    union = distributed_parallel_retrieve(args, k)                      # reference semantics (default): k per shard
+    run = distributed_parallel_retrieve(args, k, global_topk=True)      # one search over the concatenated index
     assert all(len(v) == k for v in run.values()) and all(len(v) >= k for v in union.values())
     U.save_as_trec(run, os.path.join(tmp_path, "trec", "test.0.trec"))
     assert U.load_from_trec(os.path.join(tmp_path, "trec", "test.0.trec")).keys() == run.keys()

@@ -15,7 +15,8 @@
 #include "gemm_core.h"
 #include "gemm_core_il.h"
 #include "gemm_epilogue.h"
-#include "kernels.h"
+#include "lab.h"
+#include "gemm_core_lab.h"
 
 namespace vr {
 

@@ -14,7 +14,8 @@
 // the 32-row fragment reads (the (r & 7) swizzle of the 16x16 kernels is 2-way here).
 #include "gemm_core.h"
 #include "gemm_epilogue.h"
-#include "kernels.h"
+#include "lab.h"
+#include "gemm_core_lab.h"
 
 namespace vr {
 

@@ -8,7 +8,8 @@
 //   27: MFMA only, NO epilogue stores   28: MFMA only, NO prologue DMA   29: both (dispatch + MFMA)
 #include "gemm_core.h"
 #include "gemm_epilogue.h"
-#include "kernels.h"
+#include "lab.h"
+#include "gemm_core_lab.h"
 
 namespace vr {
 

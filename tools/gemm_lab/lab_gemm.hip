@@ -6,19 +6,23 @@
 //   residual), :293-335 (SwiGLU MLP).
 // Main loops: gemm_core.h (128x128 4-wave tile; 256x256 8-wave tile).  Roofline: MFMA.
 #include "gemm_core.h"
+#include "gemm_core_lab.h"
+#include "gemm_core_mid.h"
+#include "gemm_core_stag.h"
 #include "gemm_core_il.h"
-#include "kernels.h"
+#include "lab.h"
 #include "gemm_epilogue.h"
+#include <cstdlib>
 
 namespace vr {
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+template <int EPI, bool GLDS>
+__global__ __launch_bounds__(256) void lab_gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = p.N / GEMM_BN;
     const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM;
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    // grouped rasterisation (see gemm256_bf16_kernel): with few m-tiles (decoder, M ~ 2k) GM = all of
+    // grouped rasterisation (see lab_gemm256_bf16_kernel): with few m-tiles (decoder, M ~ 2k) GM = all of
     // them, i.e. n-major order, so a W tile is fetched once and shared by every m-tile instead of W
     // being streamed once per m-row (PMC: 904 MB fetched for a 63 MB gate/up GEMM before this).
     const int GM = p.raster_gm > 0 ? p.raster_gm : 1;
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     gemm_acc_t acc;
     gemm_zero(acc);
-    gemm_mainloop(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
+    (GLDS ? gemm_mainloop : gemm_mainloop_reg)(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -48,10 +52,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         gemm_epilogue_row<EPI>(acc[i], p, m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64, lane >> 4);
 }
 
-// 256x256 tile, 8 waves (see gemm_core.h, gemm_core_il.h).  W must have readable rows up to the next multiple of
+// 256x256 tile, 8 waves (see gemm_core.h).  W must have readable rows up to the next multiple of
 // 256 (the engine pads weights); columns >= N are not stored.
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
+template <int EPI, int MODE>   // MODE 0: 2-stage, 1: BK32 x 4 stages, 2: 2-stage with mid-tile prefetch
+__global__ __launch_bounds__(512, 2) void lab_gemm256_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = (p.N + G256_BN - 1) / G256_BN;
     const int tiles_m = (p.M + G256_BM - 1) / G256_BM;
@@ -76,7 +80,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     const int Ks = p.K / ks;
     const bf16_t* Ap = (const bf16_t*)p.A + (size_t)split * Ks;
     const bf16_t* Wp = (const bf16_t*)p.W + (size_t)split * Ks;
-    gemm256_mainloop_il(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    if constexpr (MODE == 4) gemm256_mainloop_il(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else if constexpr (MODE == 1) gemm256_mainloop_p4(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else if constexpr (MODE == 3) gemm256_mainloop_stag(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else if constexpr (MODE == 2) gemm256_mainloop_mid(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
+    else gemm256_mainloop(acc, Ap, p.lda, Wp, p.ldw, m0, n0, Ks, smem);
 
     if constexpr (EPI == EPI_F32) {
         if (ks > 1) {
@@ -110,14 +118,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
 
 template <int EPI>
 static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
-    GemmArgs a = a_in;
-    if (variant == GEMM_VARIANT_256IL) {
-        const int tn = (a.N + G256_BN - 1) / G256_BN, tm = (a.M + G256_BM - 1) / G256_BM;
-        if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;   // 4 is within noise of the best for big M; few m-tiles -> n-major
-        auto k = gemm256_bf16_kernel<EPI>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr = true; }
-        int grid = tn * tm;
+    const GemmArgs& a = a_in;
+    if (variant == LAB_256 || variant == LAB_256P4 || variant == LAB_256MID ||
+        variant == LAB_256STAG || variant == GEMM_VARIANT_256IL) {
+        GemmArgs a = a_in;   // (shadows the outer reference: raster_gm is filled in here)
+        const int tn = (a.N + G256_BN - 1) / G256_BN;
+        const int tiles = tn * ((a.M + G256_BM - 1) / G256_BM);
+        static const int env_gm = getenv("VR_RASTER_GM") ? atoi(getenv("VR_RASTER_GM")) : 0;   // tuning aid
+        if (env_gm > 0) a.raster_gm = env_gm;
+        if (a.raster_gm <= 0) {   // 4 is within noise of the best for big M; few m-tiles -> n-major
+            const int tm = (a.M + G256_BM - 1) / G256_BM;
+            a.raster_gm = tm <= 16 ? tm : 4;
+        }
+        const int vi = (variant == LAB_256) ? 0 : (variant == LAB_256P4) ? 1
+                     : (variant == LAB_256MID) ? 2 : (variant == LAB_256STAG) ? 3 : 4;
+        void (*k)(GemmArgs) = vi == 0 ? lab_gemm256_bf16_kernel<EPI, 0> : vi == 1 ? lab_gemm256_bf16_kernel<EPI, 1>
+                            : vi == 2 ? lab_gemm256_bf16_kernel<EPI, 2> : vi == 3 ? lab_gemm256_bf16_kernel<EPI, 3>
+                            : lab_gemm256_bf16_kernel<EPI, 4>;
+        static bool attr[5] = {false, false, false, false, false};
+        if (!attr[vi]) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr[vi] = true; }
+        int grid = tiles;
         if (a.ksplit > 1) {
             if (EPI != EPI_F32 || a.K % (a.ksplit * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
             grid *= a.ksplit;
@@ -125,23 +145,35 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), G256_SMEM_BYTES, s, a);
         return hipGetLastError();
     }
-    if (variant != GEMM_VARIANT_GLDS) return hipErrorInvalidValue;
-    if (a.ksplit > 1) return hipErrorInvalidValue;          // split-K exists on the 256-tile kernel only
+    if (a.ksplit > 1) return hipErrorInvalidValue;          // split-K exists on the 256-tile kernels only
     const int tiles = (a.N / GEMM_BN) * ((a.M + GEMM_BM - 1) / GEMM_BM);
-    if (a.raster_gm <= 0) {
-        const int tm = (a.M + GEMM_BM - 1) / GEMM_BM;
-        a.raster_gm = tm <= 32 ? tm : 4;
+    GemmArgs a2 = a_in;
+    if (a2.raster_gm <= 0) {
+        const int tm = (a2.M + GEMM_BM - 1) / GEMM_BM;
+        a2.raster_gm = tm <= 32 ? tm : 4;
     }
-    auto k = gemm_bf16_kernel<EPI>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); attr = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), GEMM_SMEM_BYTES, s, a);
+    if (variant == LAB_REG) {
+        auto k = lab_gemm_bf16_kernel<EPI, false>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); attr = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), GEMM_SMEM_BYTES, s, a2);
+    } else {
+        auto k = lab_gemm_bf16_kernel<EPI, true>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); attr = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), GEMM_SMEM_BYTES, s, a2);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
-    if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
+hipError_t launch_gemm_lab(const GemmArgs& a_in, int epi, int variant, hipStream_t s) {
+    if (a_in.M <= 0) return hipSuccess;
+    GemmArgs a = a_in;
+    if (variant == LAB_32) return launch_gemm32(a, epi, s);
+    if (variant == LAB_256P) return launch_gemm256p(a, epi, s);
+    if (variant == LAB_256T) return launch_gemm256t(a, epi, s);
+    if (variant == LAB_256W4) return launch_gemm256w4(a, epi, s);
+    if (variant >= 20 && variant <= 29) return launch_gemm_ablate(a, variant, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel
         if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID)
@@ -156,7 +188,10 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         const long t128 = (long)(a.N / 128) * ((a.M + 127) / 128);
         const double e256 = 1.25 * (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        variant = (n_ok && e256 > e128) ? GEMM_VARIANT_256IL : GEMM_VARIANT_GLDS;
+        // interleaved 256 kernel.  The persistent one (variant 10) is +5 % in an isolated loop but
+        // -15 % inside the model (A/B in one session: qkv 8.66 vs 7.33 ms/step) — it stays an experiment.
+        static const int env256 = getenv("VR_GEMM256") ? atoi(getenv("VR_GEMM256")) : 0;   // A/B aid
+        variant = (n_ok && e256 > e128) ? (env256 ? env256 : GEMM_VARIANT_256IL) : GEMM_VARIANT_GLDS;
     }
     switch (epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(a, variant, s);
@@ -170,3 +205,14 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
 }
 
 }  // namespace vr
+
+// C entry of the lab library: same argument meaning as vr_op_gemm (include/visrag_hip.h)
+extern "C" int vr_lab_gemm(int device_id, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
+                           const float* bias, const float* resid, float alpha, void* out, int ldo, const int* rope_pos,
+                           const float* rope_table, int rope_cols, int variant, void* stream) {
+    if (hipSetDevice(device_id) != hipSuccess) return 2;
+    vr::GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid;
+    a.alpha = alpha; a.out = out; a.ldo = ldo; a.rope_pos = rope_pos; a.rope_table = rope_table; a.rope_cols = rope_cols;
+    return vr::launch_gemm_lab(a, epilogue, variant, (hipStream_t)stream) == hipSuccess ? 0 : 2;
+}

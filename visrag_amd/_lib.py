@@ -72,7 +72,9 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # VISRAG_HIP_LIB: load another build of the SAME library (tools/ab_*.py: tagged A/B builds of
+    # `python -m visrag_amd.build --tag ...`); it is not a fallback — a missing file still raises
+    p = path or os.environ.get("VISRAG_HIP_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise VisragHipError(
             f"{p} not found: the HIP extension is not built. Run `python -m visrag_amd.build` "

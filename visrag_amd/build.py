@@ -1,7 +1,11 @@
 """Build libvisrag_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m visrag_amd.build            # incremental
+    python -m visrag_amd.build                      # incremental
     python -m visrag_amd.build --force
+    python -m visrag_amd.build --tag p1 -DVR_ATTN_PIPE=1   # A/B build: libvisrag_hip_p1.so (tools/ only)
+
+Tagged builds exist for kernel A/B measurements (tools/ab_*.py load them by path); the product
+and the tests always use the untagged library.
 """
 from __future__ import annotations
 
@@ -9,13 +13,20 @@ import os
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
+from typing import Iterable, List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libvisrag_hip.so")
-SOURCES = ["gemm.hip", "gemm192.hip", "gemm32.hip", "gemm_ablate.hip", "gemm256p.hip", "gemm256t.hip", "gemm256w4.hip", "norm.hip", "attention.hip", "misc.hip", "search.hip", "search256.hip", "search_small.hip", "search_bigk.hip", "resize.hip", "pack.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemm192.hip", "norm.hip", "attention.hip", "misc.hip", "search.hip", "search256.hip",
+           "search_small.hip", "search_bigk.hip", "resize.hip", "pack.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# attention.hip: relaxed NaN handling only (infinities are honoured: masked scores are -inf).  Without it
+# every fmaxf of an MFMA result is preceded by a canonicalising v_max_f32 x, x (32 extra VALU per tile).
+FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
+
+
+def lib_path(tag: str = "") -> str:
+    return os.path.join(HERE, f"libvisrag_hip{'_' + tag if tag else ''}.so")
 
 
 def _hipcc() -> str:
@@ -34,20 +45,28 @@ def _newest_header() -> float:
     return t
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, tag: str = "", defines: Optional[Iterable[str]] = None) -> str:
+    defines = list(defines or [])
+    obj_dir = os.path.join(HERE, "build" + ("_" + tag if tag else ""))
+    lib = lib_path(tag)
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     hdr = _newest_header()
+    stamp = os.path.join(obj_dir, "defines.txt")
+    if tag:     # a changed define set invalidates a tagged build
+        old = open(stamp).read() if os.path.exists(stamp) else None
+        if old != " ".join(defines):
+            force = True
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr):
-            jobs.append((s, o))
+            jobs.append((s, o, src))
 
     def compile_one(job):
-        s, o = job
-        cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+        s, o, name = job
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(name, []), *defines, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")
@@ -57,17 +76,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     if jobs:
         if verbose:
-            print(f"[visrag_amd.build] compiling {len(jobs)} file(s) for gfx950", file=sys.stderr)
+            print(f"[visrag_amd.build] compiling {len(jobs)} file(s) for gfx950" + (f" (tag {tag})" if tag else ""),
+                  file=sys.stderr)
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if jobs or not os.path.exists(LIB) or force:
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
+    objs: List[str] = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
+    if jobs or not os.path.exists(lib) or force:
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    return LIB
+    if tag:
+        with open(stamp, "w") as f:
+            f.write(" ".join(defines))
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else ""
+    print(build(force="--force" in argv, tag=tag, defines=[a for a in argv if a.startswith("-D")]))

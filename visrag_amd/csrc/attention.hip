@@ -18,17 +18,29 @@
 //                              for the key order (2ks*16 + g*4 + j | (2ks+1)*16 + g*4 + j), and
 //                              the two tr-reads of a V fragment fetch exactly those keys)
 // A lane therefore owns one query column (q = lane & 15): max / sum are 16 in-lane values plus
-// a 2-step cross-lane reduction, and the final O row is 4 consecutive d per lane (8-byte stores).
-// head_dim 72: QK^T = 2 x (16x16x32) + 1 x (16x16x16) MFMA (d padded to 80 with zeros in LDS),
-// PV = 5 d-fragments (80).  Row pitch 160 B (288 B for head_dim 128) = 8 mod 64 dwords makes
-// both the b128 K reads and the tr_b16 V reads bank-conflict free.
+// a 2-step cross-lane reduction (v_permlane16_swap / v_permlane32_swap: register to register, no
+// LDS crossbar), and the final O row is 4 consecutive d per lane (8-byte stores).
+// head_dim 72: QK^T = 3 x (16x16x32) MFMA per fragment (d padded with zeros), PV = 5 d-fragments
+// (80; column 72 of V holds 1.0, so the PV MFMA also produces the softmax row sums).  Row pitch
+// 160 B (288 B for head_dim 128) = 8 mod 64 dwords makes both the b128 K reads and the tr_b16 V
+// reads bank-conflict free.
+//
+// Pipeline (template PIPE):
+//   0  one K/V slot, two barriers per tile (kept for head_dim 128: two slots would not fit the
+//      static LDS limit; the resampler call is < 0.2 % of an encode step)
+//   1  two K/V slots: tile t+1 is written into the other slot at the top of iteration t and the
+//      global loads of tile t+2 are issued right behind it — ONE barrier per tile, no LDS
+//      write -> barrier -> read chain on the critical path
+//   2  as 1, and the score MFMAs run one tile AHEAD: S(t+1) = K[t+1] Q^T is issued before the
+//      softmax of tile t, so the exp/convert VALU work of a wave overlaps its own matrix work
+//      instead of relying on the co-resident wave (K slots therefore lead the V slots by a tile)
+// K / V tiles come in through buffer loads whose descriptor ends at the sequence's last row:
+// rows past kv_len read as zeros (no address clamping, no per-tile 64-bit address arithmetic).
 // Roofline: MFMA (4*N^2*D flop per head).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
-
-#ifndef VR_ATTN_TAIL_X16
-#define VR_ATTN_TAIL_X16 0
-#endif
 
 namespace vr {
 
@@ -47,7 +59,21 @@ __device__ __forceinline__ bf16x4 lds_tr_read(const char* p) {
     return __builtin_bit_cast(bf16x4, r);
 }
 
-template <int HD, int QF>
+// reductions over the four lanes that hold the same query column (lane ^ 16, lane ^ 32)
+__device__ __forceinline__ float col4_max(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float col4_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <int HD, int QF, int PIPE>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     using C = AttnCfg<HD>;
     constexpr int K32 = C::K32, DFRAGS = C::DFRAGS, PITCH = C::PITCH;
@@ -55,10 +81,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     constexpr int CPR = HD / 8;                   // 16-byte chunks per global row
     constexpr int QT = 64 * QF;                   // query rows per workgroup
     constexpr int NCH = (ATT_KV * CPR + 255) / 256;   // staging chunks per thread
+    constexpr int NB = PIPE ? 2 : 1;              // K / V slots
+    constexpr int SLOT = ATT_KV * PITCH;
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * ATT_KV * PITCH];
-    char* Ks = smem;
-    char* Vs = smem + ATT_KV * PITCH;
+    __shared__ __attribute__((aligned(16))) char smem[2 * NB * SLOT];   // K slots, then V slots
+    char* const Ks = smem;
+    char* const Vs = smem + NB * SLOT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -72,24 +100,22 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const int q_row0 = p.cu_q[b];                      // rows of `out` (and of q unless shared)
     const int q_len = p.cu_q[b + 1] - q_row0;
     const int qs = qt * QT;                            // first query of this tile (seq-relative)
-    if (qs >= q_len) return;
+    if (qs >= q_len || kv_len <= 0) return;
 
     const bf16_t* qbase = (const bf16_t*)p.q + (size_t)(p.q_shared ? 0 : q_row0) * p.ldq + h * HD;
     const bf16_t* kbase = (const bf16_t*)p.k + (size_t)kv0 * p.ldk + h * HD;
     const bf16_t* vbase = (const bf16_t*)p.v + (size_t)kv0 * p.ldv + h * HD;
+    // (wave-uniform: everything above derives from blockIdx and kernel arguments)
+    const auto krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, ((kv_len - 1) * p.ldk + HD) * 2, 0x00020000);
+    const auto vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, ((kv_len - 1) * p.ldv + HD) * 2, 0x00020000);
 
-    // ---- zero the LDS row padding once (staging never overwrites it)
+    // ---- zero the LDS (row padding stays zero: staging never overwrites it)
     for (int i = tid; i < (int)sizeof(smem) / 16; i += 256)
         reinterpret_cast<u32x4*>(smem)[i] = u32x4{0, 0, 0, 0};
 
-    if constexpr (TAIL) {   // V column HD (= 72) := 1.0 in every key row: the PV MFMA then also yields the row sums
-        __syncthreads();
-        if (tid < ATT_KV) *reinterpret_cast<bf16_t*>(Vs + tid * PITCH + HD * 2) = (bf16_t)1.0f;
-    }
-
     // ---- Q fragments (B operand of S^T): lane holds Q[q = fr][d = ks*32 + fq*8 .. +7]
     bf16x8 qf[QF][K32];
-    bf16x4 qtail[QF];
+    bf16x8 qtail[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         const int q = qs + (wave * QF + f) * 16 + fr;
@@ -100,10 +126,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             if (ok) raw = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + ks * 32 + fq * 8);
             qf[f][ks] = __builtin_bit_cast(bf16x8, raw);
         }
-        u32x2 rt = {0, 0};
-        if (TAIL && ok && K32 * 32 + fq * 4 < HD)
-            rt = *reinterpret_cast<const u32x2*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 4);
-        qtail[f] = __builtin_bit_cast(bf16x4, rt);
+        u32x4 rt = {0, 0, 0, 0};   // tail: d = 64 + fq*4 .. +3 in k-slots 0..3, zeros in 4..7 (K uses the same map)
+        if (TAIL && ok && K32 * 32 + fq * 4 < HD) {
+            const u32x2 t2 = *reinterpret_cast<const u32x2*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 4);
+            rt[0] = t2[0]; rt[1] = t2[1];
+        }
+        qtail[f] = __builtin_bit_cast(bf16x8, rt);
     }
 
     f32x4 o[QF][DFRAGS];
@@ -120,93 +148,87 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const int n_tiles = (kv_end + ATT_KV - 1) / ATT_KV;
     const float sc = p.scale * 1.44269504088896340736f;   // exp2 domain
 
-    // Staging: every thread moves NCH 16-byte chunks of K and of V per tile.  Loads are
-    // UNCONDITIONAL (row clamped to the last valid key): a load under a divergent branch makes
-    // hipcc drain vmcnt(0) at the join and lose the prefetch.  Rows past kv_len are therefore
-    // copies of the last key — harmless, their scores are masked to -inf (P = 0).
+    // ---- staging: every thread moves NCH 16-byte chunks of K and of V per tile (threads past the
+    //      last chunk repeat it: same bytes, same address)
     u32x4 rk[NCH], rv[NCH];
-    int st_key[NCH], st_ch[NCH];
+    int st_lds[NCH];
+    unsigned st_k[NCH], st_v[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = min(tid + i * 256, ATT_KV * CPR - 1);
-        st_key[i] = c / CPR; st_ch[i] = c % CPR;
+        const int key = c / CPR, ch = c % CPR;
+        st_lds[i] = key * PITCH + ch * 16;
+        st_k[i] = (unsigned)(key * p.ldk + ch * 8) * 2u;
+        st_v[i] = (unsigned)(key * p.ldv + ch * 8) * 2u;
     }
-    auto load_tile = [&](int tile) {
+    const unsigned k_step = (unsigned)(ATT_KV * p.ldk) * 2u, v_step = (unsigned)(ATT_KV * p.ldv) * 2u;
+    auto load_k = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int kg = min(tile * ATT_KV + st_key[i], kv_len - 1);
-            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)kg * p.ldk + st_ch[i] * 8);
-            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)kg * p.ldv + st_ch[i] * 8);
-        }
+        for (int i = 0; i < NCH; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, st_k[i] + tile * k_step, 0, 0);
     };
-    auto write_tile = [&]() {
+    auto load_v = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {   // (threads clamped to the last chunk rewrite the same bytes)
-            *reinterpret_cast<u32x4*>(Ks + st_key[i] * PITCH + st_ch[i] * 16) = rk[i];
-            *reinterpret_cast<u32x4*>(Vs + st_key[i] * PITCH + st_ch[i] * 16) = rv[i];
-        }
+        for (int i = 0; i < NCH; ++i) rv[i] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, st_v[i] + tile * v_step, 0, 0);
+    };
+    auto write_k = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(Ks + slot * SLOT + st_lds[i]) = rk[i];
+    };
+    auto write_v = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(Vs + slot * SLOT + st_lds[i]) = rv[i];
     };
 
     // per-lane LDS offsets: K rows by fragment, V tr-read base (row fq*4 + fr/4, col-quad fr%4)
     const int k_off = fr * PITCH + fq * 16;
     const int v_off = (fq * 4 + (fr >> 2)) * PITCH + (fr & 3) * 8;
 
-    load_tile(0);
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        __syncthreads();            // previous tile fully consumed (and the zero-fill done)
-        write_tile();
-        __syncthreads();
-        if (tile + 1 < n_tiles) load_tile(tile + 1);   // in flight during the MFMAs below
-
-        const int key0 = tile * ATT_KV;
-        // ---- S^T = K Q^T : all K fragments of the tile are fetched up front (each read once for
-        //      all QF q-fragments), so the LDS latency is paid once and the MFMAs run back to back
+    // ---- S^T = K Q^T for one tile: K fragments fetched up front (each read once for all QF
+    //      q-fragments); accumulators are walked ks-outermost so that dependent MFMAs are 8 apart
+    auto scores = [&](const char* Kt, f32x4 (&s)[QF][4]) {
         bf16x8 ka[4][K32];
-        bf16x4 kt[4];
+        bf16x8 kt[4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-            const char* kr = Ks + kf * 16 * PITCH + k_off;
+            const char* kr = Kt + kf * 16 * PITCH + k_off;
 #pragma unroll
             for (int ks = 0; ks < K32; ++ks) ka[kf][ks] = *reinterpret_cast<const bf16x8*>(kr + ks * 64);
-            if constexpr (TAIL) kt[kf] = *reinterpret_cast<const bf16x4*>(Ks + (kf * 16 + fr) * PITCH + K32 * 64 + fq * 8);
-        }
-        f32x4 s[QF][4];
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf) {
-#pragma unroll
-            for (int f = 0; f < QF; ++f) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < K32; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kf][ks], qf[f][ks], acc, 0, 0, 0);
-                if constexpr (TAIL) {
-#if VR_ATTN_TAIL_X16
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt[kf], qtail[f], acc, 0, 0, 0);
-#else
-                    const bf16x4 z = {};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(kt[kf], z, 0, 1, 2, 3, 4, 5, 6, 7),
-                                                                  __builtin_shufflevector(qtail[f], z, 0, 1, 2, 3, 4, 5, 6, 7),
-                                                                  acc, 0, 0, 0);
-#endif
-                }
-                s[f][kf] = acc;
+            if constexpr (TAIL) {
+                const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(Kt + (kf * 16 + fr) * PITCH + K32 * 64 + fq * 8);
+                const bf16x4 z = {};
+                kt[kf] = __builtin_shufflevector(t4, z, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
-        // V^T fragments of the first PV k-step: issued now, consumed after the softmax below
-        bf16x8 va0[DFRAGS];
 #pragma unroll
-        for (int d = 0; d < DFRAGS; ++d) {
-            const char* vr = Vs + v_off + d * 32;
-            va0[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) s[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < K32; ++ks)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    s[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kf][ks], qf[f][ks], s[f][kf], 0, 0, 0);
+        if constexpr (TAIL) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    s[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[kf], qtail[f], s[f][kf], 0, 0, 0);
         }
-        // ---- mask + online softmax; lane owns query q, keys key0 + kf*16 + fq*4 + r.
-        // VALU diet (the kernel is VALU/MFMA balanced at head_dim 72): the scale is folded into one
-        // fma per score, the running max is only raised when it grows by more than 2^MAX_SLACK
-        // (so the O rescale is a rare wave-uniform branch; P stays <= 2^MAX_SLACK, harmless in
-        // bf16/fp32), and for head_dim 72 the row sum comes out of the PV MFMA itself: column 72 of
-        // the zero-padded V tile holds 1.0, so O^T[72][q] = sum_k P[k][q].
+    };
+
+    // ---- online softmax of tile `tile` in three steps, so that the caller can put the next tile's
+    // score MFMAs between the short statistics step and the long exp / convert step.
+    // VALU diet (the kernel is VALU/MFMA balanced at head_dim 72): the scale is folded into one
+    // fma per score, the running max is only raised when it grows by more than 2^MAX_SLACK (so the
+    // O rescale is a rare wave-uniform branch; P stays <= 2^MAX_SLACK, harmless in bf16/fp32), and
+    // for head_dim 72 the row sum comes out of the PV MFMA itself (V column 72 == 1.0).
+    // 1. mask + running max (+ rare rescale of O); returns -m per q-fragment
+    auto stats = [&](f32x4 (&s)[QF][4], int tile, float (&neg_m)[QF]) {
+        const int key0 = tile * ATT_KV;
         const bool need_mask = (key0 + ATT_KV > kv_len) || (p.causal && key0 + ATT_KV > qs);
-        bf16x8 pb[QF][2];
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
             if (need_mask) {
@@ -222,8 +244,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 #pragma unroll
             for (int kf = 1; kf < 4; ++kf)
                 mx = fmaxf(mx, fmaxf(fmaxf(s[f][kf][0], s[f][kf][1]), fmaxf(s[f][kf][2], s[f][kf][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = col4_max(mx);
             const float mxs = mx * sc;
             const bool upd = mxs > m_run[f] + MAX_SLACK;       // (-inf + slack = -inf: first valid tile updates)
             if (__any(upd)) {
@@ -234,18 +255,22 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 #pragma unroll
                 for (int d = 0; d < DFRAGS; ++d) o[f][d] *= alpha;
             }
-            const float neg_m = (m_run[f] == -INFINITY) ? 0.f : -m_run[f];   // all-masked rows: exp2(-inf) = 0
+            neg_m[f] = (m_run[f] == -INFINITY) ? 0.f : -m_run[f];   // all-masked rows: exp2(-inf) = 0
+        }
+    };
+    // 2. P = exp2(s * scale - m), packed to the bf16 B operand of the PV MFMA (branch-free)
+    auto exp_pack = [&](f32x4 (&s)[QF][4], const float (&neg_m)[QF], bf16x8 (&pb)[QF][2]) {
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[f][kf][r] = __builtin_amdgcn_exp2f(fmaf(s[f][kf][r], sc, neg_m));
+                for (int r = 0; r < 4; ++r) s[f][kf][r] = __builtin_amdgcn_exp2f(fmaf(s[f][kf][r], sc, neg_m[f]));
             if constexpr (!TAIL) {
                 float rs = 0.f;
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf) rs += (s[f][kf][0] + s[f][kf][1]) + (s[f][kf][2] + s[f][kf][3]);
-                rs += __shfl_xor(rs, 16, 64);
-                rs += __shfl_xor(rs, 32, 64);
-                l_run[f] += rs;
+                l_run[f] += col4_sum(rs);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -255,24 +280,110 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
                     pb[f][ks][4 + r] = f2bf(s[f][2 * ks + 1][r]);
                 }
         }
-        // ---- O^T += V^T P^T : each V^T fragment (two transposing reads; rows (2ks)*16 + fq*4 + j
-        //      and (2ks+1)*16 + fq*4 + j) feeds all QF q-fragments
-        bf16x8 va1[DFRAGS];
+    };
+    // 3. O^T += V^T P^T: each V^T fragment (two transposing reads; rows (2ks)*16 + fq*4 + j and
+    //    (2ks+1)*16 + fq*4 + j) feeds all QF q-fragments
+    auto v_frags = [&](const char* Vt, int kstep, bf16x8 (&va)[DFRAGS]) {
 #pragma unroll
         for (int d = 0; d < DFRAGS; ++d) {
-            const char* vr = Vs + v_off + 32 * PITCH + d * 32;
-            va1[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
+            const char* vr = Vt + v_off + kstep * 32 * PITCH + d * 32;
+            va[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
         }
+    };
+    auto pv = [&](const bf16x8 (&va)[DFRAGS], const bf16x8 (&pb)[QF][2], int kstep) {
 #pragma unroll
         for (int d = 0; d < DFRAGS; ++d)
 #pragma unroll
             for (int f = 0; f < QF; ++f)
-                o[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0[d], pb[f][0], o[f][d], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < DFRAGS; ++d)
-#pragma unroll
-            for (int f = 0; f < QF; ++f)
-                o[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1[d], pb[f][1], o[f][d], 0, 0, 0);
+                o[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[d], pb[f][kstep], o[f][d], 0, 0, 0);
+    };
+    auto softmax_pv = [&](f32x4 (&s)[QF][4], const char* Vt, int tile) {
+        bf16x8 va0[DFRAGS], va1[DFRAGS], pb[QF][2];
+        float neg_m[QF];
+        v_frags(Vt, 0, va0);                     // issued now, consumed after the softmax
+        stats(s, tile, neg_m);
+        exp_pack(s, neg_m, pb);
+        v_frags(Vt, 1, va1);
+        pv(va0, pb, 0);
+        pv(va1, pb, 1);
+    };
+
+    auto set_ones = [&]() {   // V column HD (= 72) := 1.0 in every key row of every slot
+        if constexpr (TAIL) {
+            if (tid < NB * ATT_KV) *reinterpret_cast<bf16_t*>(Vs + tid * PITCH + HD * 2) = (bf16_t)1.0f;
+        }
+    };
+
+    load_k(0);
+    load_v(0);
+    __syncthreads();                // zero-fill done
+    set_ones();
+
+    if constexpr (PIPE == 0) {
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            if (tile) __syncthreads();            // previous tile fully consumed
+            write_k(0); write_v(0);
+            __syncthreads();
+            load_k(tile + 1); load_v(tile + 1);   // in flight during the MFMAs below (past the end: zeros)
+            f32x4 s[QF][4];
+            scores(Ks, s);
+            softmax_pv(s, Vs, tile);
+        }
+    } else if constexpr (PIPE == 1) {
+        write_k(0); write_v(0);
+        load_k(1); load_v(1);
+        __syncthreads();
+        // (two iterations per trip so that the slot addresses are compile-time constants)
+        auto body = [&](int tile, auto cur_c) {
+            constexpr int cur = decltype(cur_c)::value;
+            write_k(cur ^ 1); write_v(cur ^ 1);   // tile+1: its slot was last read before the previous barrier
+            load_k(tile + 2); load_v(tile + 2);
+            f32x4 s[QF][4];
+            scores(Ks + cur * SLOT, s);
+            softmax_pv(s, Vs + cur * SLOT, tile);
+            __syncthreads();
+        };
+        for (int tile = 0; tile < n_tiles; tile += 2) {
+            body(tile, std::integral_constant<int, 0>{});
+            if (tile + 1 >= n_tiles) break;
+            body(tile + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        // invariant at the top of iteration t: LDS holds K[t+1] (slot (t+1)&1) and V[t] (slot t&1),
+        // s_cur = scores of tile t, registers carry K[t+2] and V[t+1] (in flight)
+        write_k(0); write_v(0);
+        load_k(1);
+        __syncthreads();
+        f32x4 s_a[QF][4], s_b[QF][4];
+        scores(Ks, s_a);
+        write_k(1);
+        load_k(2); load_v(1);
+        __syncthreads();
+        // two iterations per trip: the two score sets swap roles (no register copies) and the slot
+        // addresses are compile-time constants
+        auto body = [&](int tile, auto cur_c, f32x4 (&s_cur)[QF][4], f32x4 (&s_nxt)[QF][4]) {
+            constexpr int cur = decltype(cur_c)::value;
+            write_k(cur); write_v(cur ^ 1);
+            load_k(tile + 3); load_v(tile + 2);
+            const char* Vt = Vs + cur * SLOT;
+            bf16x8 va0[DFRAGS], va1[DFRAGS], pb[QF][2];
+            float neg_m[QF];
+            v_frags(Vt, 0, va0);
+            stats(s_cur, tile, neg_m);
+            // one straight-line region: the score MFMAs of tile+1 (past the end: unused) run under
+            // the exp / convert VALU work of tile `tile`
+            scores(Ks + (cur ^ 1) * SLOT, s_nxt);
+            exp_pack(s_cur, neg_m, pb);
+            v_frags(Vt, 1, va1);
+            pv(va0, pb, 0);
+            pv(va1, pb, 1);
+            __syncthreads();
+        };
+        for (int tile = 0; tile < n_tiles; tile += 2) {
+            body(tile, std::integral_constant<int, 0>{}, s_a, s_b);
+            if (tile + 1 >= n_tiles) break;
+            body(tile + 1, std::integral_constant<int, 1>{}, s_b, s_a);
+        }
     }
 
     // ---- normalise and store: lane owns out[q][h*HD + d*16 + fq*4 .. +3]
@@ -297,10 +408,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
 }
 
-template <int HD, int QF>
+#ifndef VR_ATTN_PIPE
+#define VR_ATTN_PIPE 2
+#endif
+
+template <int HD, int QF, int PIPE>
 static hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
     const int q_tiles = (a.max_q + 64 * QF - 1) / (64 * QF);
-    hipLaunchKernelGGL((attention_kernel<HD, QF>), dim3(a.B * a.heads * q_tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attention_kernel<HD, QF, PIPE>), dim3(a.B * a.heads * q_tiles), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -309,9 +424,9 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if ((a.ldq | a.ldk | a.ldv) % 8 || a.ldo % 4) return hipErrorInvalidValue;
     const bool big = a.max_q > 64;
     switch (a.head_dim) {
-        case 64:  return big ? launch_t<64, 2>(a, s) : launch_t<64, 1>(a, s);
-        case 72:  return big ? launch_t<72, 2>(a, s) : launch_t<72, 1>(a, s);
-        case 128: return launch_t<128, 1>(a, s);
+        case 64:  return big ? launch_t<64, 2, VR_ATTN_PIPE>(a, s) : launch_t<64, 1, VR_ATTN_PIPE>(a, s);
+        case 72:  return big ? launch_t<72, 2, VR_ATTN_PIPE>(a, s) : launch_t<72, 1, VR_ATTN_PIPE>(a, s);
+        case 128: return launch_t<128, 1, 0>(a, s);
         default:  return hipErrorInvalidValue;
     }
 }

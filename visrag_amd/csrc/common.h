@@ -40,3 +40,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
 }
+
+// counted wait + raw barrier: lets LDS-DMA loads younger than the N-th stay in flight across the
+// barrier (__syncthreads() would drain the whole queue)
+#define VR_WAIT_VM_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")

@@ -61,14 +61,30 @@ extern "C" int vr_device_count(int* count) {
 }
 
 // ------------------------------------------------------------------------- device bufs ---
+// Owning device buffer.  A COPY is a non-owning alias (vr_model_clone shares the weight buffers of
+// its source this way); moves transfer ownership; the destructor frees what the buffer owns, so
+// temporaries are released on every return path.
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool owned = true;
+    DevBuf() = default;
+    DevBuf(const DevBuf& o) : p(o.p), bytes(o.bytes), owned(false) {}
+    DevBuf& operator=(const DevBuf& o) {
+        if (this != &o) { free(); p = o.p; bytes = o.bytes; owned = false; }
+        return *this;
+    }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; o.owned = true; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { free(); p = o.p; bytes = o.bytes; owned = o.owned; o.p = nullptr; o.bytes = 0; o.owned = true; }
+        return *this;
+    }
+    ~DevBuf() { free(); }
     int alloc(size_t n) {
         free();
         if (n == 0) n = 16;
         hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) return fail(VR_ERR_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        if (e != hipSuccess) { p = nullptr; return fail(VR_ERR_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
         bytes = n;
         e = hipMemset(p, 0, n);
         if (e != hipSuccess) return fail(VR_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
@@ -78,10 +94,21 @@ struct DevBuf {
         if (e != hipSuccess) return fail(VR_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
         return VR_OK;
     }
+    // grow-only scratch: contents undefined, no clear, no synchronisation unless it has to grow
+    int reserve(size_t n) {
+        if (p && owned && bytes >= n) return VR_OK;
+        free();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return fail(VR_ERR_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+        bytes = n;
+        return VR_OK;
+    }
     void free() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
+        owned = true;
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -141,7 +168,7 @@ struct vr_model_s {
     // pinned host arena for the small per-call arrays (ids, offsets, row maps, image pointers):
     // async H2D copies read it after vr_encode returned, `arena_ev` marks when they have run.
     char* arena = nullptr; size_t arena_cap = 0, arena_used = 0;
-    hipEvent_t arena_ev = nullptr; bool arena_pending = false;
+    hipEvent_t arena_ev = nullptr; bool arena_pending = false, arena_open = false;
 };
 
 static int arena_begin(vr_model_s* m, size_t need) {
@@ -155,6 +182,7 @@ static int arena_begin(vr_model_s* m, size_t need) {
         m->arena_cap = cap;
     }
     m->arena_used = 0;
+    m->arena_open = true;        // async copies may read the arena from here on (see vr_encode)
     return VR_OK;
 }
 static void* arena_take(vr_model_s* m, size_t bytes) {
@@ -824,10 +852,31 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     return VR_OK;
 }
 
+static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
+                       int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
+                       const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream);
+
 extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
                          int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
                          const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream) {
     if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    m->arena_open = false;
+    const int rc = encode_impl(m, slices, slice_hw, n_slices, slices_on_device, input_ids, seq_offsets, B, vision_rows,
+                               out_reps, out_on_device, stream);
+    // the pinned arena feeds async H2D copies: on EVERY exit after the first of them (a failure in
+    // the middle of the call included) mark when they have run, or the next call would overwrite
+    // the arena under copies that are still pending
+    if (m->arena_open && m->arena_ev) {
+        if (hipEventRecord(m->arena_ev, (hipStream_t)stream) == hipSuccess) m->arena_pending = true;
+        else (void)hipStreamSynchronize((hipStream_t)stream);
+    }
+    m->arena_open = false;
+    return rc;
+}
+
+static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
+                       int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
+                       const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream) {
     if (!m->finalized) return fail(VR_ERR_STATE, "vr_model_finalize() has not succeeded");
     if (B <= 0 || !input_ids || !seq_offsets || !out_reps) return fail(VR_ERR_INVALID, "empty batch or NULL argument");
     if (n_slices > 0 && (!slices || !slice_hw || !vision_rows)) return fail(VR_ERR_INVALID, "NULL slice arguments");
@@ -926,8 +975,6 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
         for (int cand = DEC_KSPLIT_MAX; cand > 1; --cand)
             if (tiles * cand <= 256 && E % (cand * 64) == 0 && m->Ip % (cand * 64) == 0) { ks = cand; break; }
         if (m->taps_on) ks = 1;          // (taps read h between the projection and the next norm)
-        static const int env_ks = getenv("VR_DEC_KSPLIT") ? atoi(getenv("VR_DEC_KSPLIT")) : -1;   // tuning aid
-        if (env_ks >= 1 && env_ks <= DEC_KSPLIT_MAX && E % (env_ks * 64) == 0 && m->Ip % (env_ks * 64) == 0 && !m->taps_on) ks = env_ks;
     }
     const size_t pstride = (size_t)T * E;
     float* part = m->w_part.as<float>();
@@ -991,8 +1038,6 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
     float* dst = out_on_device ? out_reps : m->w_out.as<float>();
     HIPCHK(launch_pool(h, seq, B, E, m->final_norm.v.as<float>(), c.rms_norm_eps, dst, tap_hidden, s));
     if (tap_hidden) VRCHK(tap_store(m, "last_hidden", tap_hidden, T, E, E, false, s));
-    HIPCHK(hipEventRecord(m->arena_ev, s));
-    m->arena_pending = true;
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out_reps, dst, (size_t)B * E * 4, hipMemcpyDeviceToHost, s));
     if (!out_on_device || (n_slices > 0 && !slices_on_device)) HIPCHK(hipStreamSynchronize(s));   // host buffers consumed
     return VR_OK;
@@ -1011,13 +1056,13 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     for (DevBuf* b : {&m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
                       &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out}) {
-        b->p = nullptr; b->bytes = 0;
+        b->free();                                 // (a non-owning alias after the copy: just forget it)
     }
     m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)
     m->taps.clear(); m->taps_on = false;
     m->prof_on = false;
     for (auto& pc : m->prof) { pc.ev.clear(); pc.used = 0; pc.ms = 0; pc.flops = 0; pc.launches = 0; }
-    m->arena = nullptr; m->arena_cap = 0; m->arena_used = 0; m->arena_ev = nullptr; m->arena_pending = false;
+    m->arena = nullptr; m->arena_cap = 0; m->arena_used = 0; m->arena_ev = nullptr; m->arena_pending = false; m->arena_open = false;
     const int r = alloc_workspace(m);
     if (r != VR_OK) { (void)vr_model_destroy(m); return r; }
     *out = m;
@@ -1211,20 +1256,24 @@ static int get_resize_tab(int dev, int in_size, int out_size, ResizeTab** out) {
     return VR_OK;
 }
 
+// grow-only staging buffers per (device, stream): the resize of a page costs no allocation, no
+// clear and no stream synchronisation, so it stays asynchronous next to another stream's batch
+struct ResizeScratch { DevBuf in, tmp; };
+static std::map<std::pair<int, void*>, ResizeScratch> g_resize_scratch;
+
 extern "C" int vr_resize_bicubic(int device_id, const uint8_t* src, int32_t src_on_device, int32_t H, int32_t W,
                                  uint8_t* dst, int32_t out_h, int32_t out_w, void* stream) {
     if (!src || !dst || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) return fail(VR_ERR_INVALID, "bad resize arguments");
     VRCHK(set_dev(device_id));
     hipStream_t s = (hipStream_t)stream;
-    DevBuf in_dev, tmp;
+    ResizeScratch& sc = g_resize_scratch[std::make_pair(device_id, stream)];
     const uint8_t* in = src;
     if (!src_on_device) {
-        VRCHK(in_dev.alloc((size_t)H * W * 3));
-        HIPCHK(hipMemcpyAsync(in_dev.p, src, (size_t)H * W * 3, hipMemcpyHostToDevice, s));
-        in = in_dev.as<uint8_t>();
+        VRCHK(sc.in.reserve((size_t)H * W * 3));
+        HIPCHK(hipMemcpyAsync(sc.in.p, src, (size_t)H * W * 3, hipMemcpyHostToDevice, s));
+        in = sc.in.as<uint8_t>();
     }
     const bool need_h = out_w != W, need_v = out_h != H;
-    int rc = VR_OK;
     if (!need_h && !need_v) {
         HIPCHK(hipMemcpyAsync(dst, in, (size_t)H * W * 3, hipMemcpyDeviceToDevice, s));
     } else {
@@ -1233,7 +1282,7 @@ extern "C" int vr_resize_bicubic(int device_id, const uint8_t* src, int32_t src_
             ResizeTab* th = nullptr;
             VRCHK(get_resize_tab(device_id, W, out_w, &th));
             uint8_t* hout = dst;
-            if (need_v) { VRCHK(tmp.alloc((size_t)H * out_w * 3)); hout = tmp.as<uint8_t>(); }
+            if (need_v) { VRCHK(sc.tmp.reserve((size_t)H * out_w * 3)); hout = sc.tmp.as<uint8_t>(); }
             HIPCHK(launch_resize_h(in, W, H, hout, out_w, th->bounds.as<int>(), th->kk.as<int>(), th->ksize, s));
             mid = hout;
         }
@@ -1243,9 +1292,8 @@ extern "C" int vr_resize_bicubic(int device_id, const uint8_t* src, int32_t src_
             HIPCHK(launch_resize_v(mid, out_w, dst, out_h, tv->bounds.as<int>(), tv->kk.as<int>(), tv->ksize, s));
         }
     }
-    HIPCHK(hipStreamSynchronize(s));     // temporaries are freed on return
-    in_dev.free(); tmp.free();
-    return rc;
+    if (!src_on_device) HIPCHK(hipStreamSynchronize(s));     // the caller may reuse its host buffer
+    return VR_OK;
 }
 
 // ------------------------------------------------------------------------------ op-level ---
@@ -1254,6 +1302,8 @@ extern "C" int vr_op_gemm(int device_id, const void* A, int32_t lda, const void*
                           int32_t ldo, const int32_t* rope_pos, const float* rope_table, int32_t rope_cols,
                           int32_t variant, void* stream) {
     if (!A || !W || !out) return fail(VR_ERR_INVALID, "NULL argument");
+    if (variant != GEMM_VARIANT_GLDS && variant != GEMM_VARIANT_AUTO && variant != GEMM_VARIANT_192 && variant != GEMM_VARIANT_256IL)
+        return fail(VR_ERR_INVALID, "variant %d: 0 (128^2 tile), 3 (auto), 7 (256x192 tile) or 9 (256^2 tile)", variant);
     if ((variant == 7 ? N % 192 : N % 128) || K % 64 || M <= 0) return fail(VR_ERR_INVALID, "need N %% 128 == 0 (192 for variant 7), K %% 64 == 0");
     if (epilogue == EPI_RESID && !resid) return fail(VR_ERR_INVALID, "EPI_RESID needs resid");
     if (epilogue == EPI_ROPE && (!rope_pos || !rope_table)) return fail(VR_ERR_INVALID, "EPI_ROPE needs tables");

@@ -7,9 +7,10 @@ namespace vr {
 
 // ---- GEMM (gemm.hip) ---------------------------------------------------------------------
 enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_SWIGLU = 4, EPI_ROPE = 5 };
-// GLDS/REG: 128x128 tile (LDS-DMA / register staging); 256: 256x256 8-wave tile (needs W and A
-// readable up to the next multiple of 256 rows); AUTO picks by M.
-enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_REG = 1, GEMM_VARIANT_256 = 2, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_256P4 = 4, GEMM_VARIANT_256MID = 5, GEMM_VARIANT_256STAG = 6, GEMM_VARIANT_192 = 7, GEMM_VARIANT_32 = 8, GEMM_VARIANT_256IL = 9, GEMM_VARIANT_256P = 10, GEMM_VARIANT_256T = 11, GEMM_VARIANT_256W4 = 12 };
+// GLDS: 128x128 4-wave tile; 256IL: 256x256 8-wave tile (needs W and A readable up to the next
+// multiple of 256 rows); 192: 256x192 tile for N % 192 == 0; AUTO picks by shape.  (The ids of the
+// retired experiment variants live on in tools/gemm_lab.)
+enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_192 = 7, GEMM_VARIANT_256IL = 9 };
 
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M_pad][lda]
@@ -26,21 +27,12 @@ struct GemmArgs {
     const float* rope_table;         // f32 [max_pos][64] = cos[32] | sin[32]
     int rope_cols;                   // columns < rope_cols are rotated (q and k), rest copied (v)
     int raster_gm;                   // 256-tile kernels: m-tiles per raster group (0 = choose by W size)
-    int direct_store;                // tuning aid (VR_EPI_DIRECT=1): skip the LDS-staged coalesced epilogue
     int ksplit;                      // 256-tile kernels, EPI_F32 only: split K over ksplit workgroups per tile;
     size_t split_stride;             //   split s writes its partial product to out + s * split_stride (elements)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // 256x192 tile (gemm192.hip): N % 192 == 0, epilogues BF16 / GELU / F32 / RESID only
 hipError_t launch_gemm192(const GemmArgs& a, int epilogue, hipStream_t s);
-// 256x256 tile on v_mfma_f32_32x32x16_bf16 (gemm32.hip): same contract as the 256 variants
-hipError_t launch_gemm32(const GemmArgs& a, int epilogue, hipStream_t s);
-// persistent 256x256 kernel: one workgroup per CU walks the tile list (gemm256p.hip)
-hipError_t launch_gemm256p(const GemmArgs& a, int epilogue, hipStream_t s);
-hipError_t launch_gemm256t(const GemmArgs& a, int epilogue, hipStream_t s);   // 256^2 + L2 touch-ahead
-hipError_t launch_gemm256w4(const GemmArgs& a, int epilogue, hipStream_t s);  // 256^2, 4 waves x (128 x 128)
-// timing ablations of the 256-tile main loop (variants 20..23, invalid results; gemm_ablate.hip)
-hipError_t launch_gemm_ablate(const GemmArgs& a, int ablation, hipStream_t s);
 
 // ---- norms (norm.hip) --------------------------------------------------------------------
 // x f32 [rows][ldx] (dim used) -> bf16 [rows][ldo]; columns [dim, ldo) are written as zero.

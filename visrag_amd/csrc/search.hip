@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_t
         const int doc0 = tile * tile_step * 128;
         gemm_acc_t acc;
         gemm_zero(acc);
-        gemm_mainloop<true>(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim,
+        gemm_mainloop(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim,
                             doc0, q0, p.dim, smem);
         // thresholds of this lane's 16 queries (4 fragments x 4 consecutive columns)
 #pragma unroll
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void search_prepass_kernel(SearchArgs p, int q
     const int doc0 = chunk * tile_step * 128;
     gemm_acc_t acc;
     gemm_zero(acc);
-    gemm_mainloop<true>(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
+    gemm_mainloop(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -363,12 +363,8 @@ int search_kprime(int k) {
 int search_prepass_floats() { return PRE_CHUNKS * PRE_GROUPS; }
 
 bool search_uses_256(int nq) {
-    static int force = -1;           // tuning aid: VR_SEARCH_TILE=128 keeps every search on the 128^2 sweep
-    if (force < 0) { const char* e = getenv("VR_SEARCH_TILE"); force = (e && atoi(e) == 128) ? 1 : 0; }
     // 17..128 queries also run faster on the 256^2 sweep (half-empty query tile and all: 0.29 vs 0.33 ms)
-    static int min256 = -1;          // tuning aid: smallest batch that takes the 256^2 sweep
-    if (min256 < 0) { const char* e = getenv("VR_SEARCH_256_MIN"); min256 = e ? atoi(e) : 17; }
-    return nq >= min256 && !force;
+    return nq >= 17;
 }
 
 int search_num_chunks(int64_t n_docs, int nq) {

@@ -238,90 +238,16 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
     }
 }
 
-// ---- merge: one wave per query over its n_chunks * 2 unsorted half-lists --------------------
-//  1. lane l takes the max over its own lists (l, l + 64, ...): 64 maxima over DISJOINT entry
-//     sets; the KP-th largest of them is <= KP distinct entries, i.e. a lower
-//     bound of the query's global KP-th best key (KEY_NONE when fewer than KP lanes saw a key);
+
+// ---- merge: one WORKGROUP per query (256 threads) over its n_chunks * 2 unsorted half-lists ---
+//  1. thread t takes the max over its own lists (t, t + 256, ...): maxima over DISJOINT entry
+//     sets; the KP-th largest of them is <= KP distinct entries, i.e. a lower bound of the
+//     query's global KP-th best key (KEY_NONE when fewer than KP threads saw a key);
 //  2. entries >= that bound are appended to LDS (ballot compaction) — typically ~20 of ~1900;
 //  3. one sort (or, for > MERGE_CAP survivors = massive ties, a merge over everything);
-//  4. fp32 re-scoring + final sort (rescore_emit).
-template <int KP>
-__global__ __launch_bounds__(256) void search_merge256_kernel(SearchArgs p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wave;
-    if (q >= p.nq) return;
-    const int lists = p.n_chunks * 2;
-    const int* cnts = p.cand_ids + (size_t)q * lists;
-    const unsigned long long* keys = p.cand_keys + (size_t)q * lists * HL_CAP;
-    __shared__ uint64_t surv[4][MERGE_CAP];
-
-    // lane = list: every lane walks its own list(s), four keys (two 16-B loads) per round
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    uint64_t m = KEY_NONE;
-    for (int l0 = 0; l0 < lists; l0 += 64) {
-        const int l = l0 + lane;
-        const int c = l < lists ? cnts[l] : 0;
-        const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)min(l, lists - 1) * HL_CAP);
-        for (int e = 0; e < c; e += 4) {
-            const u64x2 a = row[e >> 1], b2 = row[(e >> 1) + 1];      // (slots past c are never read back)
-            const uint64_t k0 = a[0], k1 = e + 1 < c ? a[1] : KEY_NONE;
-            const uint64_t k2 = e + 2 < c ? b2[0] : KEY_NONE, k3 = e + 3 < c ? b2[1] : KEY_NONE;
-            const uint64_t x = k0 > k1 ? k0 : k1, y = k2 > k3 ? k2 : k3;
-            const uint64_t z = x > y ? x : y;
-            m = z > m ? z : m;
-        }
-    }
-    const uint64_t thr = shfl_u64(wave_sort_desc(m), KP - 1);
-
-    int n = 0;
-    for (int l0 = 0; l0 < lists; l0 += 64) {
-        const int l = l0 + lane;
-        const int c = l < lists ? cnts[l] : 0;
-        int cmax = c;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
-        const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)min(l, lists - 1) * HL_CAP);
-        for (int e = 0; e < cmax; e += 4) {                          // wave-uniform trip count (ballots inside)
-            uint64_t k4[4] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-            if (e < c) {
-                const u64x2 a = row[e >> 1], b2 = row[(e >> 1) + 1];
-                k4[0] = a[0];
-                k4[1] = e + 1 < c ? a[1] : KEY_NONE;
-                k4[2] = e + 2 < c ? b2[0] : KEY_NONE;
-                k4[3] = e + 3 < c ? b2[1] : KEY_NONE;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool live = k4[u] != KEY_NONE && k4[u] >= thr;
-                const unsigned long long bal = __ballot(live);
-                if (live) {
-                    const int pos = n + __popcll(bal & ((1ull << lane) - 1));
-                    if (pos < MERGE_CAP) surv[wave][pos] = k4[u];
-                }
-                n += __popcll(bal);
-            }
-        }
-    }
-    uint64_t best = KEY_NONE;
-    if (n <= MERGE_CAP) {
-        for (int base = 0; base < n; base += 64) {
-            const uint64_t key = (base + lane < n) ? surv[wave][base + lane] : KEY_NONE;
-            best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
-        }
-    } else {
-        for (int l = 0; l < lists; ++l) {
-            const int c = cnts[l];
-            const uint64_t key = (lane < c) ? keys[(size_t)l * HL_CAP + lane] : KEY_NONE;
-            best = (l == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
-        }
-    }
-    rescore_emit<KP>(p, q, best, lane);
-}
-
-// One WORKGROUP per query (256 threads): thread = list (t, t + 256, ...), so all list walks of a
-// query run in parallel, and the four waves re-score the KP candidates concurrently.  With a few
-// hundred queries the wave-per-query merge above leaves most of the chip idle behind a chain of
-// dependent loads (128 queries: 101 us).
+//  4. fp32 re-scoring by the four waves concurrently + final sort (rescore_emit).
+// All list walks of a query run in parallel: a wave-per-query merge left most of the chip idle
+// behind a chain of dependent loads with a few hundred queries (128 queries: 101 us).
 template <int KP>
 __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     __shared__ uint64_t lm[256];
@@ -438,15 +364,10 @@ static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s)
     auto k = search_sweep256_kernel<KP>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEP256_SMEM); attr = true; }
-    static int debug = -1;     // tuning aid: VR_SWEEP_DEBUG=1 rejects every score (GEMM + scan floor of the sweep)
-    if (debug < 0) { const char* e = getenv("VR_SWEEP_DEBUG"); debug = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr, debug);
+    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    static int wgm = -1;       // tuning aid: VR_MERGE256_WG = largest nq merged by one workgroup per query
-    if (wgm < 0) { const char* e2 = getenv("VR_MERGE256_WG"); wgm = e2 ? atoi(e2) : 1 << 30; }
-    if (a.nq <= wgm) hipLaunchKernelGGL(search_merge256_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(search_merge256_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(search_merge256_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, a);   // one workgroup per query
     return hipGetLastError();
 }
 

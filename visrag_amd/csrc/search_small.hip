@@ -25,9 +25,7 @@ constexpr int SS_CH = 4;             // pair-steps per prefetch chunk
 int search_stream_chunks() { return SS_WG; }
 
 bool search_uses_stream(int nq, int dim) {
-    static int off = -1;             // tuning aid: VR_SEARCH_STREAM=0 keeps small batches on the 128^2 sweep
-    if (off < 0) { const char* e = getenv("VR_SEARCH_STREAM"); off = (e && atoi(e) == 0) ? 1 : 0; }
-    return !off && nq <= 16 && dim % 256 == 0 && dim <= 2560;
+    return nq <= 16 && dim % 256 == 0 && dim <= 2560;
 }
 
 struct StreamLds {

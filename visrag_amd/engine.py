@@ -14,8 +14,9 @@ from .config import VisRAGRetConfig
 from .preprocess import PreparedItem
 
 
-def _stream_ptr() -> int:
-    return int(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else 0
+def _stream_ptr(device: int = 0) -> int:
+    """HIP stream handle of torch's CURRENT stream ON `device` (the device the C side launches on)."""
+    return int(torch.cuda.current_stream(int(device)).cuda_stream) if torch.cuda.is_available() else 0
 
 
 def _require_gpu():
@@ -149,7 +150,7 @@ class HipEncoder:
         _lib.check(self.lib.vr_encode(
             self._h, ptrs, hw_arr, n_slices, on_dev,
             ids.ctypes.data_as(C.POINTER(C.c_int32)), seq.ctypes.data_as(C.POINTER(C.c_int32)), B,
-            vr_p, C.c_void_p(out.data_ptr()), 1, C.c_void_p(_stream_ptr())), "vr_encode")
+            vr_p, C.c_void_p(out.data_ptr()), 1, C.c_void_p(_stream_ptr(self.device))), "vr_encode")
         return out
 
     # ---- profiling (HIP events around kernel classes, see include/visrag_hip.h) -------------
@@ -212,12 +213,12 @@ class HipIndex:
             t = reps.to(torch.float32).contiguous()
             assert t.dim() == 2 and t.shape[1] == self.dim
             _lib.check(self.lib.vr_index_add(self._h, C.c_void_p(t.data_ptr()), t.shape[0],
-                                             1 if t.is_cuda else 0, C.c_void_p(_stream_ptr())), "vr_index_add")
+                                             1 if t.is_cuda else 0, C.c_void_p(_stream_ptr(self.device))), "vr_index_add")
         else:
             a = np.ascontiguousarray(reps, dtype=np.float32)
             assert a.ndim == 2 and a.shape[1] == self.dim
             _lib.check(self.lib.vr_index_add(self._h, C.c_void_p(a.ctypes.data), a.shape[0], 0,
-                                             C.c_void_p(_stream_ptr())), "vr_index_add")
+                                             C.c_void_p(_stream_ptr(self.device))), "vr_index_add")
 
     def search(self, queries, k: int):
         """-> (scores [nq,k] f32, ids [nq,k] i64); torch cuda tensors in -> cuda tensors out,
@@ -229,7 +230,7 @@ class HipIndex:
             ix = torch.empty((nq, k), dtype=torch.int64, device=q.device)
             _lib.check(self.lib.vr_index_search(self._h, C.c_void_p(q.data_ptr()), nq, k,
                                                 C.c_void_p(sc.data_ptr()), C.c_void_p(ix.data_ptr()), 1,
-                                                C.c_void_p(_stream_ptr())), "vr_index_search")
+                                                C.c_void_p(_stream_ptr(self.device))), "vr_index_search")
             return sc, ix
         q = np.ascontiguousarray(queries.numpy() if isinstance(queries, torch.Tensor) else queries,
                                  dtype=np.float32)
@@ -238,7 +239,7 @@ class HipIndex:
         ix = np.empty((nq, k), dtype=np.int64)
         _lib.check(self.lib.vr_index_search(self._h, C.c_void_p(q.ctypes.data), nq, k,
                                             C.c_void_p(sc.ctypes.data), C.c_void_p(ix.ctypes.data), 0,
-                                            C.c_void_p(_stream_ptr())), "vr_index_search")
+                                            C.c_void_p(_stream_ptr(self.device))), "vr_index_search")
         return sc, ix
 
 
@@ -251,7 +252,8 @@ def topk_merge(scores: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, t
     ids = ids.contiguous().to(torch.int64)
     os_ = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
     oi = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
-    _lib.check(lib.vr_topk_merge(scores.device.index or 0, C.c_void_p(scores.data_ptr()), C.c_void_p(ids.data_ptr()),
+    dev = scores.device.index or 0
+    _lib.check(lib.vr_topk_merge(dev, C.c_void_p(scores.data_ptr()), C.c_void_p(ids.data_ptr()),
                                  n_parts, nq, k, C.c_void_p(os_.data_ptr()), C.c_void_p(oi.data_ptr()),
-                                 C.c_void_p(_stream_ptr())), "vr_topk_merge")
+                                 C.c_void_p(_stream_ptr(dev))), "vr_topk_merge")
     return os_, oi

@@ -31,7 +31,7 @@ def resize_bicubic(img, size: Tuple[int, int], device: int = 0) -> torch.Tensor:
         H, W = a.shape[:2]
         src, on_dev = C.c_void_p(a.ctypes.data), 0
     _lib.check(lib.vr_resize_bicubic(device, src, on_dev, H, W, C.c_void_p(out.data_ptr()), oh, ow,
-                                     C.c_void_p(int(torch.cuda.current_stream().cuda_stream))), "vr_resize_bicubic")
+                                     C.c_void_p(int(torch.cuda.current_stream(int(device)).cuda_stream))), "vr_resize_bicubic")
     return out
 
 
@@ -65,10 +65,14 @@ def prepare_item_gpu(text: str, image, tokenizer, cfg, max_inp_length: Optional[
     dev_slices: List[torch.Tensor] = []
     if image is None:
         return prepare_item(text, None, tokenizer, cfg, max_inp_length), dev_slices
-    dev_slices, grid = slice_image_gpu(image, cfg, device)
     ph = image_placeholder(tokenizer, cfg.query_num)
-    if grid is not None:
-        ph += get_grid_placeholder(tokenizer, grid, cfg.query_num)
+    if cfg.slice_mode:
+        dev_slices, grid = slice_image_gpu(image, cfg, device)
+        if grid is not None:
+            ph += get_grid_placeholder(tokenizer, grid, cfg.query_num)
+    else:   # slice_mode=False: the image as it is, one plain placeholder (modeling_visrag_ret.py:70-72)
+        a = np.asarray(image.convert("RGB") if hasattr(image, "convert") else image, dtype=np.uint8)
+        dev_slices = [torch.from_numpy(np.ascontiguousarray(a)).to(f"cuda:{device}")]
     it = prepare_item(ph + "\n" + text, None, tokenizer, cfg, max_inp_length)
     it.slices = list(dev_slices)        # device tensors: HipEncoder.encode_items passes them on as they are
     return it, dev_slices

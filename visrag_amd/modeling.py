@@ -55,11 +55,16 @@ class DRModelForInference:
     # ---- construction -----------------------------------------------------------------------
     @classmethod
     def build(cls, model_args=None, cfg: Optional[VisRAGRetConfig] = None,
-              state_dict: Optional[Iterable[Tuple[str, torch.Tensor]]] = None, device: int = 0,
+              state_dict: Optional[Iterable[Tuple[str, torch.Tensor]]] = None, device: Optional[int] = None,
               max_images: int = 32, max_tokens: int = 4096, max_seqs: int = 64, pipeline: int = 2, **_):
         """`model_args` needs `.model_name_or_path` (a HF checkpoint dir with *.safetensors /
         pytorch_model*.bin and config.json) unless `state_dict` is given; `.pooling` and
-        `.normalize` are honoured like the reference (arguments.py)."""
+        `.normalize` are honoured like the reference (arguments.py).
+
+        `device=None` (what the unchanged driver passes, driver/eval.py:124-127) resolves like the
+        reference's `encoding_args.device`: this process's LOCAL_RANK under torchrun, else torch's
+        current device — one process per GPU, never "all ranks on GPU 0"."""
+        device = default_device() if device is None else _device_index(device)
         pooling = getattr(model_args, "pooling", "wmean") if model_args is not None else "wmean"
         normalize = getattr(model_args, "normalize", True) if model_args is not None else True
         path = getattr(model_args, "model_name_or_path", None) if model_args is not None else None
@@ -87,8 +92,21 @@ class DRModelForInference:
     def eval(self):
         return self
 
-    def to(self, *_a, **_k):
+    def to(self, device=None, *_a, **_k):
+        """The reference driver calls `model.to(encoding_args.device)` after build()
+        (driver/eval.py:128-129).  Weights already live on the build device: the same device is a
+        no-op, a different one is refused (silently staying put would send every rank to one GPU)."""
+        if device is None or isinstance(device, torch.dtype):
+            return self
+        want = _device_index(device)
+        if want is not None and want != self.encoder.device:
+            raise RuntimeError(f"model was built on cuda:{self.encoder.device}, to({device!r}) asks for cuda:{want}: "
+                               "set LOCAL_RANK / torch.cuda.set_device() before build(), or pass build(device=...)")
         return self
+
+    @property
+    def device(self) -> torch.device:
+        return torch.device(f"cuda:{self.encoder.device}")
 
     # ---- reference API ----------------------------------------------------------------------
     def encode(self, items: Optional[Dict], is_query: bool = False, tokenizer=None,
@@ -147,6 +165,35 @@ class DRModelForInference:
         return DROutput(q_reps=q_reps, p_reps=p_reps)
 
     __call__ = forward
+
+
+def default_device() -> int:
+    """cuda index of this process: LOCAL_RANK (torchrun / torch.distributed.run) if set, else
+    torch's current device."""
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None and lr.strip() != "":
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        return int(lr) % n if n else int(lr)
+    return int(torch.cuda.current_device()) if torch.cuda.is_available() else 0
+
+
+def _device_index(device) -> Optional[int]:
+    """int | 'cuda' | 'cuda:3' | torch.device -> cuda index ('cuda' = this process's default); None for
+    anything that is not a cuda device spec (e.g. a dtype passed to .to())."""
+    if isinstance(device, bool):
+        return None
+    if isinstance(device, int):
+        return device
+    if isinstance(device, str):
+        try:
+            device = torch.device(device)
+        except (RuntimeError, ValueError):
+            return None
+    if isinstance(device, torch.device):
+        if device.type != "cuda":
+            raise RuntimeError(f"visrag_amd runs on HIP devices only (got {device}); there is no CPU fallback")
+        return default_device() if device.index is None else int(device.index)
+    return None
 
 
 @torch.no_grad()
