@@ -4,6 +4,8 @@ deterministic synthetic checkpoint (visrag_amd/synth.py) and stand-in tokenizer.
 
     python oracle/gen_golden.py            # tiny-dims fixtures (seconds)
     python oracle/gen_golden.py --full     # + full MiniCPM-V-2.0 dims, 2 pages + 2 queries (minutes)
+    python oracle/gen_golden.py --config1  # ONLY BASELINE config 1: full dims, 64 pages 448^2 (bs 16) + 16 queries
+                                           # through the reference encode + retrieve (top-3), ~10 min on 8 cores
 
 Runs only in the build container (the reference tree does not travel to the GPU box);
 the resulting fixtures are committed.
@@ -110,12 +112,61 @@ def reference_retrieve(p_reps, q_reps, n_shards, k):
     return res, trec_text
 
 
+def config1(n_pages=64, n_queries=16, bs=16, k=3):
+    """BASELINE.json configs[0]: 64 page images (448x448) + 16 text queries through the reference's
+    DRModelForInference in batches of 16 (README.md:146), CPU fp32, then the reference's
+    distributed_parallel_retrieve top-3 over the pickle shards (4 shards of 16 pages).  The fixture
+    keeps the embeddings, the full 16 x 64 score matrix, the ranked top-(k+1) and the rank-k / rank-(k+1)
+    gap per query (identical top-k is asserted where the gap exceeds 2x tolerance)."""
+    import time
+    from PIL import Image
+    cfg = full_config()
+    sd = synth_state_dict(cfg, 0)
+    dr = ref_harness.build_reference_dr_model(cfg, sd)
+    tok = StandInTokenizer(cfg.vocab_size)
+    pages = synth_pages(n_pages, size=448, seed=0)
+    queries = [QUERY_PREFIX + q for q in synth_queries(n_queries, seed=0)]
+    P, t0 = [], time.time()
+    with torch.no_grad():
+        for lo in range(0, n_pages, bs):
+            imgs = [Image.fromarray(a) for a in pages[lo:lo + bs]]
+            o = dr(passage={"id": [str(i) for i in range(lo, lo + len(imgs))], "text": [""] * len(imgs), "image": imgs},
+                   tokenizer=tok, max_inp_length=2048)
+            P.append(o.p_reps.numpy())
+            print(f"pages {lo + len(imgs)}/{n_pages}  {time.time() - t0:.0f}s", flush=True)
+        t_pages = time.time() - t0
+        t1 = time.time()
+        o = dr(query={"id": [str(i) for i in range(n_queries)], "text": queries, "image": [None] * n_queries},
+               tokenizer=tok, max_inp_length=512)
+        t_q = time.time() - t1
+    P = np.concatenate(P).astype(np.float32)
+    Q = o.q_reps.numpy().astype(np.float32)
+    res, trec = reference_retrieve(P, Q, n_shards=4, k=k)          # union of per-shard top-k (reference semantics)
+    S = Q @ P.T
+    order = np.argsort(-S, axis=1, kind="stable")[:, :k + 1]
+    top_scores = np.take_along_axis(S, order, 1)
+    gap = top_scores[:, k - 1] - top_scores[:, k]
+    # the reference's result must contain the brute-force top-k with the same scores
+    for qi in range(n_queries):
+        for j in range(k):
+            assert abs(res[f"q{qi}"][f"doc{order[qi, j]}"] - top_scores[qi, j]) < 1e-6
+    np.savez_compressed(os.path.join(GOLD, "config1_full.npz"), p_reps=P, q_reps=Q, scores=S.astype(np.float32),
+                        top_ids=order.astype(np.int32), top_scores=top_scores.astype(np.float32), gap=gap.astype(np.float32),
+                        trec=np.array(trec), n_pages=n_pages, n_queries=n_queries, k=k, page_seed=0, query_seed=0,
+                        ref_seconds=np.array([t_pages, t_q], dtype=np.float32), ref_threads=torch.get_num_threads())
+    print("config1_full: pages/s", n_pages / t_pages, "queries/s", n_queries / t_q, "min gap", float(gap.min()),
+          "median gap", float(np.median(gap)), "threads", torch.get_num_threads())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--config1", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_grad_enabled(False)
+    if a.config1:
+        return config1()
 
     # ---- tiny dims: 4 single-slice pages (112x112), 2 sliced pages, 3 queries ----------
     cfg = tiny_config()

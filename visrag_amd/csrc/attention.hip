@@ -34,8 +34,14 @@
 //   2  as 1, and the score MFMAs run one tile AHEAD: S(t+1) = K[t+1] Q^T is issued before the
 //      softmax of tile t, so the exp/convert VALU work of a wave overlaps its own matrix work
 //      instead of relying on the co-resident wave (K slots therefore lead the V slots by a tile)
-// K / V tiles come in through buffer loads whose descriptor ends at the sequence's last row:
-// rows past kv_len read as zeros (no address clamping, no per-tile 64-bit address arithmetic).
+//   3  as 1, but the tiles are staged by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+//      instruction, five per wave and tile) instead of registers + ds_write_b128: no staging
+//      VGPRs (-24: three workgroups per CU instead of two), no LDS-write instructions (the
+//      160-byte pitch makes ds_write_b128 2-way conflicted: 37 % extra LDS cycles, probe_lds.hip)
+//      and no vmcnt stall in front of the writes.  The DMA image is lane-linear; lanes that would
+//      hit a row's padding chunk are masked off, so the zeros / 1.0 column written once stay put.
+// PIPE 0..2: K / V tiles come in through buffer loads whose descriptor ends at the sequence's last
+// row: rows past kv_len read as zeros (no address clamping, no per-tile 64-bit address arithmetic).
 // Roofline: MFMA (4*N^2*D flop per head).
 #include <type_traits>
 
@@ -74,7 +80,7 @@ __device__ __forceinline__ float col4_sum(float v) {
 }
 
 template <int HD, int QF, int PIPE>
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnArgs p) {
     using C = AttnCfg<HD>;
     constexpr int K32 = C::K32, DFRAGS = C::DFRAGS, PITCH = C::PITCH;
     constexpr bool TAIL = C::TAIL != 0;
@@ -82,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     constexpr int QT = 64 * QF;                   // query rows per workgroup
     constexpr int NCH = (ATT_KV * CPR + 255) / 256;   // staging chunks per thread
     constexpr int NB = PIPE ? 2 : 1;              // K / V slots
+    constexpr bool DMA = PIPE >= 3;
     constexpr int SLOT = ATT_KV * PITCH;
 
     __shared__ __attribute__((aligned(16))) char smem[2 * NB * SLOT];   // K slots, then V slots
@@ -126,11 +133,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             if (ok) raw = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + ks * 32 + fq * 8);
             qf[f][ks] = __builtin_bit_cast(bf16x8, raw);
         }
-        u32x4 rt = {0, 0, 0, 0};   // tail: d = 64 + fq*4 .. +3 in k-slots 0..3, zeros in 4..7 (K uses the same map)
-        if (TAIL && ok && K32 * 32 + fq * 4 < HD) {
-            const u32x2 t2 = *reinterpret_cast<const u32x2*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 4);
-            rt[0] = t2[0]; rt[1] = t2[1];
-        }
+        // tail MFMA (d = 64..95 window): lanes fq == 0 carry the real d = 64..71, every other k-slot of Q
+        // is zero — so the K operand of those slots may be ANY finite LDS content (see scores())
+        u32x4 rt = {0, 0, 0, 0};
+        if (TAIL && ok && fq == 0) rt = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + K32 * 32);
         qtail[f] = __builtin_bit_cast(bf16x8, rt);
     }
 
@@ -148,36 +154,79 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     const int n_tiles = (kv_end + ATT_KV - 1) / ATT_KV;
     const float sc = p.scale * 1.44269504088896340736f;   // exp2 domain
 
-    // ---- staging: every thread moves NCH 16-byte chunks of K and of V per tile (threads past the
-    //      last chunk repeat it: same bytes, same address)
-    u32x4 rk[NCH], rv[NCH];
-    int st_lds[NCH];
-    unsigned st_k[NCH], st_v[NCH];
+    // ---- staging through registers (PIPE 0..2): every thread moves NCH 16-byte chunks of K and of V
+    //      per tile (threads past the last chunk repeat it: same bytes, same address)
+    constexpr int NCHR = DMA ? 1 : NCH;
+    u32x4 rk[NCHR], rv[NCHR];
+    int st_lds[NCHR];
+    unsigned st_k[NCHR], st_v[NCHR];
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = min(tid + i * 256, ATT_KV * CPR - 1);
-        const int key = c / CPR, ch = c % CPR;
-        st_lds[i] = key * PITCH + ch * 16;
-        st_k[i] = (unsigned)(key * p.ldk + ch * 8) * 2u;
-        st_v[i] = (unsigned)(key * p.ldv + ch * 8) * 2u;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = min(tid + i * 256, ATT_KV * CPR - 1);
+            const int key = c / CPR, ch = c % CPR;
+            st_lds[i] = key * PITCH + ch * 16;
+            st_k[i] = (unsigned)(key * p.ldk + ch * 8) * 2u;
+            st_v[i] = (unsigned)(key * p.ldv + ch * 8) * 2u;
+        }
     }
     const unsigned k_step = (unsigned)(ATT_KV * p.ldk) * 2u, v_step = (unsigned)(ATT_KV * p.ldv) * 2u;
     auto load_k = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, st_k[i] + tile * k_step, 0, 0);
+        for (int i = 0; i < NCHR; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, st_k[i] + tile * k_step, 0, 0);
     };
     auto load_v = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) rv[i] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, st_v[i] + tile * v_step, 0, 0);
+        for (int i = 0; i < NCHR; ++i) rv[i] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, st_v[i] + tile * v_step, 0, 0);
     };
     auto write_k = [&](int slot) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(Ks + slot * SLOT + st_lds[i]) = rk[i];
+        for (int i = 0; i < NCHR; ++i) *reinterpret_cast<u32x4*>(Ks + slot * SLOT + st_lds[i]) = rk[i];
     };
     auto write_v = [&](int slot) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(Vs + slot * SLOT + st_lds[i]) = rv[i];
+        for (int i = 0; i < NCHR; ++i) *reinterpret_cast<u32x4*>(Vs + slot * SLOT + st_lds[i]) = rv[i];
     };
+
+    // ---- staging by LDS-DMA (PIPE 3).  A tile image is ATT_KV rows x CPL 16-byte chunks, lane-linear
+    //      per wave instruction (64 chunks = 1 KiB: buffer_load_dwordx4 ... lds); the 2 * NDMA
+    //      instructions of a K + V tile pair are dealt round-robin to the 4 waves.  Lanes that would
+    //      land on a padding chunk are switched off (EXEC): the zero fill and the 1.0 column written
+    //      once at kernel start stay in place.  Rows past kv_len are out of the descriptor's range and
+    //      arrive as zeros.
+    constexpr int CPL = PITCH / 16;
+    constexpr int NDMA = ATT_KV * CPL / 64;
+    constexpr int NI = DMA ? (2 * NDMA + 3) / 4 : 1;
+    unsigned doff[NI];             // byte offset of this lane's chunk inside tile 0 (K or V)
+    unsigned dmask = 0;            // bit i: this lane carries payload in instruction slot i
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = wave_u + 4 * i;                 // instruction index: K tile 0..NDMA-1, V tile NDMA..
+            const int isv = j >= NDMA;
+            const int c = (j - isv * NDMA) * 64 + lane;
+            const int row = c / CPL, ch = c % CPL;
+            doff[i] = (unsigned)(row * (isv ? p.ldv : p.ldk) + ch * 8) * 2u;
+            if (ch < CPR && j < 2 * NDMA) dmask |= 1u << i;
+        }
+    }
+    auto dma_issue = [&](int tile_k, int slot_k, int tile_v, int slot_v) {   // K tile -> K slot, V tile -> V slot
+        if constexpr (DMA) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int j = wave_u + 4 * i;
+                const int isv = j >= NDMA;
+                char* dst = (isv ? Vs + slot_v * SLOT : Ks + slot_k * SLOT) + (j - isv * NDMA) * 1024;
+                const unsigned off = doff[i] + (isv ? (unsigned)tile_v * v_step : (unsigned)tile_k * k_step);
+                if (dmask & (1u << i)) {
+                    if (isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, VR_LDS(dst), 16, off, 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, VR_LDS(dst), 16, off, 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto dma_tile = [&](int tile, int slot) { dma_issue(tile, slot, tile, slot); };
 
     // per-lane LDS offsets: K rows by fragment, V tr-read base (row fq*4 + fr/4, col-quad fr%4)
     const int k_off = fr * PITCH + fq * 16;
@@ -193,11 +242,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             const char* kr = Kt + kf * 16 * PITCH + k_off;
 #pragma unroll
             for (int ks = 0; ks < K32; ++ks) ka[kf][ks] = *reinterpret_cast<const bf16x8*>(kr + ks * 64);
-            if constexpr (TAIL) {
-                const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(Kt + (kf * 16 + fr) * PITCH + K32 * 64 + fq * 8);
-                const bf16x4 z = {};
-                kt[kf] = __builtin_shufflevector(t4, z, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+            // tail: one b128 read per lane at d = 64 + fq*8.  fq 0: the real d 64..71; fq 1: the row's zero
+            // padding; fq 2, 3: the first bytes of the NEXT row (finite K data, or the start of the next
+            // slot / the V slots after the last row) — multiplied by Q's zero k-slots
+            if constexpr (TAIL) kt[kf] = *reinterpret_cast<const bf16x8*>(kr + K32 * 64);
         }
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
@@ -284,10 +332,38 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     // 3. O^T += V^T P^T: each V^T fragment (two transposing reads; rows (2ks)*16 + fq*4 + j and
     //    (2ks+1)*16 + fq*4 + j) feeds all QF q-fragments
     auto v_frags = [&](const char* Vt, int kstep, bf16x8 (&va)[DFRAGS]) {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int d = 0; d < DFRAGS; ++d) {
-            const char* vr = Vt + v_off + kstep * 32 * PITCH + d * 32;
-            va[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int d = 0; d < DFRAGS; ++d) {
+                const char* vr = Vt + v_off + kstep * 32 * PITCH + d * 32;
+                va[d] = __builtin_shufflevector(lds_tr_read(vr), lds_tr_read(vr + 16 * PITCH), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        } else {
+            // PIPE 3: the transposing reads go through inline asm.  hipcc cannot see that the tr-read
+            // builtin does not alias the LDS-DMA of the OTHER slot and puts `s_waitcnt vmcnt(0)` in
+            // front of the first one — which would wait for the tile that was requested moments ago.
+            // Hidden in asm the reads are ours to count: v_wait() below (lgkmcnt(0), naming every
+            // destination so that no consumer can be scheduled above it) closes them.
+            const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(Vt) +
+                                  (unsigned)(v_off + kstep * 32 * PITCH);
+            u32x2 lo[DFRAGS], hi[DFRAGS];
+#pragma unroll
+            for (int d = 0; d < DFRAGS; ++d) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[d]) : "v"(base), "i"(d * 32) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d]) : "v"(base), "i"(d * 32 + 16 * PITCH) : "memory");
+            }
+#pragma unroll
+            for (int d = 0; d < DFRAGS; ++d)
+                va[d] = __builtin_bit_cast(bf16x8, u32x4{lo[d][0], lo[d][1], hi[d][0], hi[d][1]});
+        }
+    };
+    auto v_wait = [&](bf16x8 (&va)[DFRAGS]) {
+        if constexpr (DMA) {
+            static_assert(!DMA || DFRAGS == 4 || DFRAGS == 5, "operand list below");
+            if constexpr (DFRAGS == 5)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]));
         }
     };
     auto pv = [&](const bf16x8 (&va)[DFRAGS], const bf16x8 (&pb)[QF][2], int kstep) {
@@ -304,7 +380,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         stats(s, tile, neg_m);
         exp_pack(s, neg_m, pb);
         v_frags(Vt, 1, va1);
+        v_wait(va0);
         pv(va0, pb, 0);
+        v_wait(va1);
         pv(va1, pb, 1);
     };
 
@@ -314,8 +392,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         }
     };
 
-    load_k(0);
-    load_v(0);
+    if constexpr (!DMA) { load_k(0); load_v(0); }
     __syncthreads();                // zero-fill done
     set_ones();
 
@@ -347,6 +424,55 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
             body(tile, std::integral_constant<int, 0>{});
             if (tile + 1 >= n_tiles) break;
             body(tile + 1, std::integral_constant<int, 1>{});
+        }
+    } else if constexpr (PIPE == 3) {
+        // (dsrc points at tile 0 after the setup above; every dma_tile call moves it one tile on)
+        dma_tile(0, 0);
+        __syncthreads();                          // (the LDS-DMA in flight makes this wait vmcnt(0) too)
+        auto body = [&](int tile, auto cur_c) {
+            constexpr int cur = decltype(cur_c)::value;
+            if (tile + 1 < n_tiles) dma_tile(tile + 1, cur ^ 1);   // its slot was last read before the previous barrier
+            f32x4 s[QF][4];
+            scores(Ks + cur * SLOT, s);
+            softmax_pv(s, Vs + cur * SLOT, tile);
+            __syncthreads();                      // tile+1 landed (vmcnt(0) + barrier), slot `cur` free
+        };
+        for (int tile = 0; tile < n_tiles; tile += 2) {
+            body(tile, std::integral_constant<int, 0>{});
+            if (tile + 1 >= n_tiles) break;
+            body(tile + 1, std::integral_constant<int, 1>{});
+        }
+    } else if constexpr (PIPE == 4) {
+        // LDS-DMA staging AND scores one tile ahead: at the top of iteration t the LDS holds K[t+1]
+        // (slot (t+1)&1) and V[t] (slot t&1), s_cur = scores of tile t; the iteration requests K[t+2]
+        // and V[t+1] (rows past the end arrive as zeros)
+        dma_tile(0, 0);
+        __syncthreads();
+        dma_issue(1, 1, 0, 0);                    // K[1]; the V half re-fetches V[0] into its own slot (harmless)
+        f32x4 s_a[QF][4], s_b[QF][4];
+        scores(Ks, s_a);
+        __syncthreads();
+        auto body = [&](int tile, auto cur_c, f32x4 (&s_cur)[QF][4], f32x4 (&s_nxt)[QF][4]) {
+            constexpr int cur = decltype(cur_c)::value;
+            dma_issue(tile + 2, cur, tile + 1, cur ^ 1);
+            const char* Vt = Vs + cur * SLOT;
+            bf16x8 va0[DFRAGS], va1[DFRAGS], pb[QF][2];
+            float neg_m[QF];
+            v_frags(Vt, 0, va0);
+            stats(s_cur, tile, neg_m);
+            scores(Ks + (cur ^ 1) * SLOT, s_nxt);
+            exp_pack(s_cur, neg_m, pb);
+            v_frags(Vt, 1, va1);
+            v_wait(va0);
+            pv(va0, pb, 0);
+            v_wait(va1);
+            pv(va1, pb, 1);
+            __syncthreads();
+        };
+        for (int tile = 0; tile < n_tiles; tile += 2) {
+            body(tile, std::integral_constant<int, 0>{}, s_a, s_b);
+            if (tile + 1 >= n_tiles) break;
+            body(tile + 1, std::integral_constant<int, 1>{}, s_b, s_a);
         }
     } else {
         // invariant at the top of iteration t: LDS holds K[t+1] (slot (t+1)&1) and V[t] (slot t&1),
@@ -409,7 +535,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 }
 
 #ifndef VR_ATTN_PIPE
-#define VR_ATTN_PIPE 2
+#define VR_ATTN_PIPE 3
+#endif
+#ifndef VR_ATTN_QF
+#define VR_ATTN_QF 2
 #endif
 
 template <int HD, int QF, int PIPE>
@@ -419,13 +548,21 @@ static hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    if (a.B <= 0 || a.max_q <= 0) return hipSuccess;
-    if ((a.ldq | a.ldk | a.ldv) % 8 || a.ldo % 4) return hipErrorInvalidValue;
+hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
+    if (a_in.B <= 0 || a_in.max_q <= 0) return hipSuccess;
+    if ((a_in.ldq | a_in.ldk | a_in.ldv) % 8 || a_in.ldo % 4) return hipErrorInvalidValue;
+    const AttnArgs& a = a_in;
+    // q-fragments per wave: 2 (32 rows) for long sequences; PIPE 0 (single slot, no pipeline prologue) is the
+    // fastest form for the one- or two-tile sequences of the decoder (68-token pages: 13.8 vs 15.7 us)
     const bool big = a.max_q > 64;
+    const bool tiny = a.max_q <= 128;
     switch (a.head_dim) {
-        case 64:  return big ? launch_t<64, 2, VR_ATTN_PIPE>(a, s) : launch_t<64, 1, VR_ATTN_PIPE>(a, s);
-        case 72:  return big ? launch_t<72, 2, VR_ATTN_PIPE>(a, s) : launch_t<72, 1, VR_ATTN_PIPE>(a, s);
+        case 64:
+            if (tiny) return big ? launch_t<64, 2, 0>(a, s) : launch_t<64, 1, 0>(a, s);
+            return launch_t<64, VR_ATTN_QF, VR_ATTN_PIPE>(a, s);
+        case 72:
+            if (tiny) return big ? launch_t<72, 2, 0>(a, s) : launch_t<72, 1, 0>(a, s);
+            return launch_t<72, VR_ATTN_QF, VR_ATTN_PIPE>(a, s);
         case 128: return launch_t<128, 1, 0>(a, s);
         default:  return hipErrorInvalidValue;
     }
