@@ -182,17 +182,6 @@ int vr_op_gemm(int device_id, const void* A, int32_t lda, const void* W, int32_t
                const float* resid, float alpha, void* out, int32_t ldo,
                const int32_t* rope_pos, const float* rope_table, int32_t rope_cols,
                int32_t variant, void* stream);
-/* The "LN fold" pair of a SigLIP block (vision_transformer.py:142-143,155-156: x = x + proj(attn(..)); then
- * norm -> linear), as the engine runs it — no LayerNorm pass:
- *   h   <- h + alpha * (A Wp^T + bp)        256x192 kernel; also emits bf16(h) and per-row statistics
- *   out  = epi(LN(h; gamma, beta, eps) W2^T + b2)   GEMM on the raw bf16 rows, gamma folded into W2,
- *                                           mean / rstd applied in the epilogue (epi 0 = bf16, 1 = erf-GELU)
- * A bf16 [M_pad256][Kp], Wp bf16 [D][Kp], h f32 [M_pad256][D] (in/out), W2 bf16 [N2_pad256][D], out bf16 [M][N2];
- * D % 192 == 0 and <= 1152, N2 % 128 == 0, Kp % 64 == 0.  variant as in vr_op_gemm (consumer GEMM). */
-int vr_op_ln_fold_pair(int device_id, const void* A, int32_t Kp, const void* Wp, const float* bp, float alpha,
-                       float* h, int32_t M, int32_t D, const float* gamma, const float* beta, float eps,
-                       const void* W2, const float* b2, int32_t N2, int32_t epilogue, void* out,
-                       int32_t variant, void* stream);
 /* y = LN(x) (kind 0, affine, eps) or RMSNorm(x) (kind 1): x f32 [rows][dim] -> bf16 [rows][ldo]. */
 int vr_op_norm(int device_id, int32_t kind, const float* x, int32_t rows, int32_t dim,
                const float* weight, const float* bias, float eps, void* out, int32_t ldo,

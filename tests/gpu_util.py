@@ -57,18 +57,3 @@ def op_attention(q, k, v, cu_q, cu_kv, heads, hd, max_q, causal, q_shared, scale
                                    int(q_shared), float(scale), None), "vr_op_attention")
     torch.cuda.synchronize()
     return out
-
-
-def op_ln_fold_pair(A, Wp, bp, alpha, h, gamma, beta, eps, W2, b2, epilogue, variant=3):
-    """h [M,D] f32 (updated in place, returned), out [M,N2] bf16 = epi(LN(h_new) @ W2^T + b2)."""
-    lib = _lib.load()
-    M, Kp = A.shape
-    D, N2 = Wp.shape[0], W2.shape[0]
-    Ap, hp = pad_rows(A), pad_rows(h.to(torch.float32))
-    W2p = pad_rows(W2)
-    out = torch.zeros((M, N2), dtype=torch.bfloat16, device=A.device)
-    _lib.check(lib.vr_op_ln_fold_pair(A.device.index or 0, P(Ap), Kp, P(Wp.contiguous()), P(bp), float(alpha), P(hp), M, D,
-                                      P(gamma), P(beta), float(eps), P(W2p), P(b2), N2, epilogue, P(out), variant, None),
-               "vr_op_ln_fold_pair")
-    torch.cuda.synchronize()
-    return hp[:M], out

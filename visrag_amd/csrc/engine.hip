@@ -117,9 +117,6 @@ struct Linear {            // bf16 [n_pad][k_pad] (+ f32 bias [n_pad])
     DevBuf w, b;
     int n = 0, k = 0, n_pad = 0, k_pad = 0;
     bool has_w = false, has_b = false;
-    // LN fold (ViT qkv / fc1): weight scaled by the preceding LayerNorm's gamma, its column sums, and the
-    // bias with the beta term folded in (built by vr_model_finalize from w / b and the norm vectors)
-    DevBuf wf, cs, bf;
 };
 struct Vec { DevBuf v; bool ok = false; };   // f32 vector (norm weights / biases)
 
@@ -162,8 +159,6 @@ struct vr_model_s {
     DevBuf w_im2col, w_hvit, w_xn, w_qkv, w_att, w_mlp, w_kv32, w_xkv, w_KV, w_ratt, w_rout, w_rln;
     DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact, w_part;   // w_part: split-K partial products [3][T][E] f32
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
-    DevBuf w_stat;                            // LN fold: f32 [Dp/96][Mcap][2] row-statistics partials
-    bool ln_fold = false;                     // ViT LayerNorms folded into the GEMMs around them (needs Dp % 192 == 0)
     std::map<std::string, Tap> taps;
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
     // stream, elapsed times summed lazily in vr_model_get_profile
@@ -264,7 +259,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
     if (!m->borrowed) {
-        auto fl = [](Linear& l) { l.w.free(); l.b.free(); l.wf.free(); l.cs.free(); l.bf.free(); };
+        auto fl = [](Linear& l) { l.w.free(); l.b.free(); };
         fl(m->patch); fl(m->r_kvproj); fl(m->r_kv); fl(m->r_out); fl(m->r_proj);
         for (auto& b : m->blocks) { fl(b.qkv); fl(b.proj); fl(b.fc1); fl(b.fc2); b.n1w.v.free(); b.n1b.v.free(); b.n2w.v.free(); b.n2b.v.free(); }
         for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); l.ln1.v.free(); l.ln2.v.free(); }
@@ -278,7 +273,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     for (DevBuf* b : {&m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
                       &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
-                      &m->w_pix, &m->w_out, &m->w_stat})
+                      &m->w_pix, &m->w_out})
         b->free();
     delete m;
     return VR_OK;
@@ -591,7 +586,6 @@ static int alloc_workspace(vr_model_s* m) {
     VRCHK(m->w_rowmap.alloc((size_t)R * 4));
     VRCHK(m->w_imgptr.alloc((size_t)c.max_images * 8));
     VRCHK(m->w_out.alloc((size_t)c.max_seqs * E * 4));
-    VRCHK(m->w_stat.alloc((size_t)(Dp / 96 + 1) * M * 2 * 4));
     return VR_OK;
 }
 
@@ -669,25 +663,6 @@ extern "C" int vr_model_finalize(vr_model_t m) {
             }
         VRCHK(m->rope.alloc(tab.size() * 4));
         HIPCHK(hipMemcpy(m->rope.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-    }
-    // ---- LN fold: gamma into the qkv / fc1 weights of every ViT block (DESIGN.md "LN fold")
-    m->ln_fold = (m->Dp % 192 == 0) && (m->Dp / 96 <= 12);
-    if (m->ln_fold) {
-        auto fold = [&](Linear& L, const Vec& g, const Vec& b) -> int {
-            const size_t rows = (size_t)pad256(L.n);
-            VRCHK(L.wf.alloc(rows * L.k_pad * 2));
-            VRCHK(L.cs.alloc(rows * 4));
-            VRCHK(L.bf.alloc(rows * 4));
-            HIPCHK(launch_ln_fold_weight(L.w.p, L.n, L.k, L.k_pad, g.v.as<float>(), b.v.as<float>(),
-                                         L.has_b ? L.b.as<float>() : nullptr, L.wf.p, L.cs.as<float>(), L.bf.as<float>(), 0));
-            return VR_OK;
-        };
-        for (int n = 0; n < c.vit_depth; ++n) {
-            VitBlock& b = m->blocks[n];
-            VRCHK(fold(b.qkv, b.n1w, b.n1b));
-            VRCHK(fold(b.fc1, b.n2w, b.n2b));
-        }
-        HIPCHK(hipDeviceSynchronize());
     }
     if (!m->w_h.p) VRCHK(alloc_workspace(m));
     m->finalized = true;
@@ -800,36 +775,20 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     const int* cu_qry = m->w_cu.as<int>() + (n + 1);
 
     float* h = m->w_hvit.as<float>();
-    // LN fold: every GEMM that writes the fp32 residual stream h (patch embed, proj, fc2) also writes
-    // bf16(h) into w_xn and the per-96-column row statistics into w_stat; qkv / fc1 then run on the raw
-    // bf16 rows with gamma-scaled weights and apply mean / rstd in their epilogue — no LayerNorm pass.
-    const bool fold = m->ln_fold;
-    const int nparts = Dp / 96;
-    auto producer = [&](GemmArgs& a) {
-        if (fold) { a.out_bf16 = m->w_xn.p; a.ld_bf16 = Dp; a.stat_part = m->w_stat.as<float>(); a.stat_dim = D; a.stat_stride = (int)m->Mcap; }
-    };
-    auto consumer = [&](GemmArgs& a, const Linear& L) {
-        if (fold) {
-            a.W = L.wf.p; a.bias = L.bf.as<float>();
-            a.ln_part = m->w_stat.as<float>(); a.ln_nparts = nparts; a.ln_dim = D; a.ln_eps = c.vit_ln_eps;
-            a.ln_colsum = L.cs.as<float>(); a.stat_stride = (int)m->Mcap;
-        }
-    };
     // K1+K2+K3: normalise + im2col, patch GEMM + bias + resampled pos-embed -> fp32 residual stream
     HIPCHK(launch_im2col((const uint8_t* const*)m->w_imgptr.p, n, H, W, P, m->w_im2col.p, m->Kpe_p, s));
     {
         GemmArgs a = gemm_args(m->w_im2col.p, m->Kpe_p, m->patch, M, h, Dp);
         a.rowbias = g->vit_pos.as<float>(); a.rowbias_period = N; a.rowbias_ld = Dp; a.rowbias_cols = Dp;
-        producer(a);
-        HIPCHK(launch_gemm(a, EPI_F32, fold ? GEMM_VARIANT_192 : GEMM_VARIANT_AUTO, s));
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s));
     }
     if (first_group) VRCHK(tap_store(m, "vit_embed", h, N, D, Dp, false, s));
     const int ldqkv = pad128(3 * D);
     for (int l = 0; l < c.vit_depth; ++l) {
         const VitBlock& b = m->blocks[l];
-        if (!fold) HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
+        HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_QKV, s));
-        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); consumer(a, b.qkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s)); }
+        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_QKV, 2.0 * M * D * 3 * D, s));
         {
             AttnArgs a{};
@@ -843,14 +802,14 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
             VRCHK(prof_end(m, VR_PROF_VIT_ATTN, 4.0 * n * (double)N * N * D, s));
         }
         VRCHK(prof_begin(m, VR_PROF_VIT_PROJ, s));
-        { GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h; producer(a); HIPCHK(launch_gemm(a, EPI_RESID, fold ? GEMM_VARIANT_192 : GEMM_VARIANT_AUTO, s)); }
+        { GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_PROJ, 2.0 * M * D * D, s));
-        if (!fold) HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
+        HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC1, s));
-        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); consumer(a, b.fc1); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_AUTO, s)); }
+        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_FC1, 2.0 * M * D * m->F, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC2, s));
-        { GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h; producer(a); HIPCHK(launch_gemm(a, EPI_RESID, fold ? GEMM_VARIANT_192 : GEMM_VARIANT_AUTO, s)); }
+        { GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_FC2, 2.0 * M * D * m->F, s));
         if (l == 0 && first_group) VRCHK(tap_store(m, "vit_block0", h, N, D, Dp, false, s));
     }
@@ -1096,7 +1055,7 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     m->borrowed = true;
     for (DevBuf* b : {&m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
-                      &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out, &m->w_stat}) {
+                      &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out}) {
         b->free();                                 // (a non-owning alias after the copy: just forget it)
     }
     m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)
@@ -1376,38 +1335,5 @@ extern "C" int vr_op_attention(int device_id, const void* q, int32_t ldq, const 
     a.cu_kv = cu_kv; a.B = B; a.heads = heads; a.head_dim = head_dim; a.max_q = max_q; a.causal = causal;
     a.q_shared = q_shared; a.scale = scale;
     HIPCHK(launch_attention(a, (hipStream_t)stream));
-    return VR_OK;
-}
-
-// LN-fold pair, exactly as a SigLIP block runs it (parity tests): producer GEMM with the residual epilogue on
-// the 256x192 kernel (emits bf16(h) + row statistics), then the consumer GEMM on the raw bf16 rows with the
-// gamma-folded weight.  Temporaries live for the call only.
-extern "C" int vr_op_ln_fold_pair(int device_id, const void* A, int32_t Kp, const void* Wp, const float* bp, float alpha,
-                                  float* h, int32_t M, int32_t D, const float* gamma, const float* beta, float eps,
-                                  const void* W2, const float* b2, int32_t N2, int32_t epilogue, void* out,
-                                  int32_t variant, void* stream) {
-    if (!A || !Wp || !h || !gamma || !beta || !W2 || !out) return fail(VR_ERR_INVALID, "NULL argument");
-    if (D % 192 || D / 96 > 12 || N2 % 128 || Kp % 64 || M <= 0) return fail(VR_ERR_INVALID, "need D %% 192 == 0, D <= 1152, N2 %% 128 == 0, Kp %% 64 == 0");
-    if (epilogue != EPI_BF16 && epilogue != EPI_GELU) return fail(VR_ERR_INVALID, "consumer epilogue must be 0 (bf16) or 1 (GELU)");
-    VRCHK(set_dev(device_id));
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t Mp = pad256l(M);
-    DevBuf hb, stat, wf, cs, bf;
-    VRCHK(hb.alloc((size_t)Mp * D * 2));
-    VRCHK(stat.alloc((size_t)(D / 96) * Mp * 2 * 4));
-    VRCHK(wf.alloc((size_t)pad256(N2) * D * 2));
-    VRCHK(cs.alloc((size_t)pad256(N2) * 4));
-    VRCHK(bf.alloc((size_t)pad256(N2) * 4));
-    HIPCHK(launch_ln_fold_weight(W2, N2, D, D, gamma, beta, b2, wf.p, cs.as<float>(), bf.as<float>(), s));
-    GemmArgs a{};
-    a.A = A; a.lda = Kp; a.W = Wp; a.ldw = Kp; a.M = M; a.N = D; a.K = Kp; a.bias = bp; a.resid = h; a.alpha = alpha;
-    a.out = h; a.ldo = D; a.out_bf16 = hb.p; a.ld_bf16 = D; a.stat_part = stat.as<float>(); a.stat_dim = D; a.stat_stride = (int)Mp;
-    HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_192, s));
-    GemmArgs b{};
-    b.A = hb.p; b.lda = D; b.W = wf.p; b.ldw = D; b.M = M; b.N = N2; b.K = D; b.bias = bf.as<float>(); b.alpha = 1.f;
-    b.out = out; b.ldo = N2; b.ln_part = stat.as<float>(); b.ln_nparts = D / 96; b.ln_dim = D; b.ln_eps = eps;
-    b.ln_colsum = cs.as<float>(); b.stat_stride = (int)Mp;
-    HIPCHK(launch_gemm(b, epilogue, variant, s));
-    HIPCHK(hipStreamSynchronize(s));          // temporaries are released on return
     return VR_OK;
 }

@@ -27,36 +27,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     const int gm = min(GM, tiles_m - g * GM);
     const int m0 = (g * GM + r % gm) * GEMM_BM, n0 = (r / gm) * GEMM_BN;
 
-    // LN fold (consumer): thread t < 128 fetches the statistics partials of row m0 + t now (the loads fly
-    // under the main loop) and publishes (rstd, mu * rstd) in LDS behind the operand stages afterwards
-    f32x2* lnrow = nullptr;
-    LnRowPartials lnp;
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-        if (p.ln_part) {
-            lnrow = reinterpret_cast<f32x2*>(smem + GEMM_SMEM_BYTES);
-            if (threadIdx.x < GEMM_BM) ln_load_partials(p, m0 + threadIdx.x, lnp);
-        }
-    }
-
     gemm_acc_t acc;
     gemm_zero(acc);
     gemm_mainloop(acc, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.W, p.ldw, m0, n0, p.K, smem);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-        if (lnrow) {
-            if (threadIdx.x < GEMM_BM) lnrow[threadIdx.x] = ln_finish(p, lnp);
-            __syncthreads();
-        }
-    }
     if constexpr (EPI == EPI_RESID) {
         if (!p.rowmap) { gemm_epilogue_resid_tile<4, 4, 4>(acc, p, m0 + wm * 64 + (lane & 15), n0 + wn * 64, lane >> 4); return; }
     }
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
         // coalesced stores through the idle LDS stages (the main loop ends with a barrier): 8 KiB per wave
         if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
-            gemm_epilogue_tile_lds<EPI, 4>(acc, p, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * 8192, lnrow ? lnrow + wm * 64 : nullptr);
+            gemm_epilogue_tile_lds<EPI, 4>(acc, p, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * 8192);
             return;
         }
     }
@@ -88,15 +71,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     const int gm = min(GM, tiles_m - g * GM);         // last group may be shorter
     const int m0 = (g * GM + r % gm) * G256_BM, n0 = (r / gm) * G256_BN;
 
-    f32x2* lnrow = nullptr;                   // LN fold (consumer), see gemm_bf16_kernel
-    LnRowPartials lnp;
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-        if (p.ln_part) {
-            lnrow = reinterpret_cast<f32x2*>(smem + G256_SMEM_BYTES);
-            if (threadIdx.x < G256_BM) ln_load_partials(p, m0 + threadIdx.x, lnp);
-        }
-    }
-
     gemm256_acc_t acc;
     gemm256_zero(acc);
     const int Ks = p.K / ks;
@@ -119,19 +93,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-        if (lnrow) {
-            if (threadIdx.x < G256_BM) lnrow[threadIdx.x] = ln_finish(p, lnp);
-            __syncthreads();
-        }
-    }
     if constexpr (EPI == EPI_RESID) {
         if (!p.rowmap) { gemm_epilogue_resid_tile<8, 4, 4>(acc, p, m0 + wm * 128 + (lane & 15), n0 + wn * 64, lane >> 4); return; }
     }
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
         // (every main loop ends with a workgroup barrier: the stages are free, 16 KiB per wave)
         if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
-            gemm_epilogue_tile_lds<EPI, 8>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * 16384, lnrow ? lnrow + wm * 128 : nullptr);
+            gemm_epilogue_tile_lds<EPI, 8>(acc, p, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * 16384);
             return;
         }
     }
@@ -148,13 +116,13 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
         if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;   // 4 is within noise of the best for big M; few m-tiles -> n-major
         auto k = gemm256_bf16_kernel<EPI>;
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES + G256_BM * 8); attr = true; }
+        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr = true; }
         int grid = tn * tm;
         if (a.ksplit > 1) {
             if (EPI != EPI_F32 || a.K % (a.ksplit * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
             grid *= a.ksplit;
         }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), G256_SMEM_BYTES + (a.ln_part ? G256_BM * 8 : 0), s, a);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), G256_SMEM_BYTES, s, a);
         return hipGetLastError();
     }
     if (variant != GEMM_VARIANT_GLDS) return hipErrorInvalidValue;
@@ -166,19 +134,13 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
     }
     auto k = gemm_bf16_kernel<EPI>;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES + GEMM_BM * 8); attr = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), GEMM_SMEM_BYTES + (a.ln_part ? GEMM_BM * 8 : 0), s, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); attr = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), GEMM_SMEM_BYTES, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
-    // LN fold: consumers are the bf16-output epilogues with vector-aligned shapes; producers the 256x192 kernel
-    if (a.ln_part && ((epi != EPI_BF16 && epi != EPI_GELU) || !a.ln_colsum || a.ln_nparts < 1 || a.ln_nparts > 12 ||
-                      a.ln_nparts * 96 < a.ln_dim || (a.N & 7) || (a.ldo & 7) || a.stat_stride < a.M || a.rowmap))
-        return hipErrorInvalidValue;
-    if (a.out_bf16 && !(variant == GEMM_VARIANT_192 || (variant == GEMM_VARIANT_AUTO && a.N % 192 == 0))) return hipErrorInvalidValue;
-    if (a.out_bf16 && variant == GEMM_VARIANT_AUTO) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel

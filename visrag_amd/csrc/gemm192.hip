@@ -100,12 +100,6 @@ __global__ __launch_bounds__(512, 2) void gemm192_bf16_kernel(GemmArgs p) {
             }
         }
     }
-    if constexpr (EPI == EPI_RESID || EPI == EPI_F32) {
-        if (p.out_bf16) {      // LN-fold producer: fp32 + bf16 outputs and the span statistics
-            gemm_epilogue_emit_tile<EPI, 4, 6, 2>(acc, p, m0 + wm * 64 + fr, n0 + wn * 96, fq, (n0 + wn * 96) / 96);
-            return;
-        }
-    }
     if constexpr (EPI == EPI_RESID) {
         gemm_epilogue_resid_tile<4, 6, 4>(acc, p, m0 + wm * 64 + fr, n0 + wn * 96, fq);
     } else {
@@ -128,9 +122,6 @@ static hipError_t launch192_t(GemmArgs a, hipStream_t s) {
 
 hipError_t launch_gemm192(const GemmArgs& a, int epi, hipStream_t s) {
     if (a.N % G192_BN || a.K % GEMM_BK) return hipErrorInvalidValue;
-    if (a.out_bf16 && ((epi != EPI_RESID && epi != EPI_F32) || !a.stat_part || a.stat_stride < a.M || a.rowmap || (a.ld_bf16 & 3)))
-        return hipErrorInvalidValue;
-    if (a.ln_part) return hipErrorInvalidValue;            // (consumers run on the 128^2 / 256^2 kernels)
     switch (epi) {
         case EPI_BF16: return launch192_t<EPI_BF16>(a, s);
         case EPI_GELU: return launch192_t<EPI_GELU>(a, s);

@@ -164,11 +164,9 @@ namespace vr {
 // parks its converted tile in its private slice of the (now idle) LDS stages, swizzled like the
 // operand tiles, and reads it back row-wise: one store instruction = 8 rows x 128 B, full lines.
 //   wl: this wave's LDS slice, MI * 2 KiB (row pitch 128 B = 64 bf16; SwiGLU rows hold 32).
-// lnrow: LDS array of this wave's rows' (rstd, mu * rstd) when the A operand is the raw input of a folded
-// LayerNorm (GemmArgs::ln_part), else null.
 template <int EPI, int MI>
 __device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], const GemmArgs& p, int mrow0, int nb,
-                                                       int lane, char* wl, const f32x2* lnrow = nullptr) {
+                                                       int lane, char* wl) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE, "bf16 outputs only");
     const int fr = lane & 15, fq = lane >> 4;
     // ---- 1. fused math in registers, bf16 tile into LDS
@@ -205,17 +203,10 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], cons
             if constexpr (EPI != EPI_ROPE) {
                 if (p.rowbias) rb = p.rowbias + (size_t)(m % p.rowbias_period) * p.rowbias_ld;
             }
-            f32x2 st = {1.f, 0.f};
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-                if (lnrow) st = lnrow[row];
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = min(nb + j * 16 + fq * 4, p.N - 4);
                 f32x4 v = acc[i][j];
-                if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-                    if (lnrow) v = v * st[0] - st[1] * *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
-                }
                 if constexpr (EPI != EPI_ROPE) {
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
@@ -251,125 +242,6 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], cons
             if (m < p.M && n < p.N) {
                 const int orow = p.rowmap ? p.rowmap[m] : m;
                 if (orow >= 0) *reinterpret_cast<u32x4*>(out + (size_t)orow * p.ldo + n) = d;
-            }
-        }
-    }
-}
-
-}  // namespace vr
-
-namespace vr {
-
-// ---- LN fold, consumer side: statistics of one A row from the producer's per-span partials -------
-// part p covers columns [96p, 96p + 96) of the row: (sum, centred sum of squares) over its valid columns.
-// Chan's parallel combination: mu = S / D,  M2 = sum_p [M2_p + n_p (mean_p - mu)^2].
-struct LnRowPartials { f32x2 v[12]; };
-constexpr int LN_MAX_PARTS = 12;     // rows up to 12 * 96 = 1152 columns
-
-__device__ __forceinline__ void ln_load_partials(const GemmArgs& p, int row, LnRowPartials& r) {
-    const int rr = min(row, p.M - 1);
-#pragma unroll
-    for (int i = 0; i < LN_MAX_PARTS; ++i) {
-        const int pi = min(i, p.ln_nparts - 1);      // (unconditional loads: parts past the end repeat the last)
-        r.v[i] = *reinterpret_cast<const f32x2*>(p.ln_part + ((size_t)pi * p.stat_stride + rr) * 2);
-    }
-}
-__device__ __forceinline__ f32x2 ln_finish(const GemmArgs& p, const LnRowPartials& r) {
-    float S = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_PARTS; ++i)
-        if (i < p.ln_nparts) S += r.v[i][0];
-    const float mu = S / (float)p.ln_dim;
-    float M2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_PARTS; ++i) {
-        const int np = min(96, p.ln_dim - i * 96);
-        if (i < p.ln_nparts && np > 0) {
-            const float d = r.v[i][0] / (float)np - mu;
-            M2 += r.v[i][1] + (float)np * d * d;
-        }
-    }
-    const float rstd = 1.0f / sqrtf(M2 / (float)p.ln_dim + p.ln_eps);
-    return f32x2{rstd, mu * rstd};
-}
-
-// ---- LN fold, producer side: epilogue of a (MI x 16 rows) x (NF x 16 columns) wave tile of the
-// 256x192 kernel.  out = acc + bias (+ rowbias) [EPI_F32]  or  resid + alpha * (acc + bias) [EPI_RESID],
-// stored as fp32 AND as bf16 (the next GEMM's A operand), plus the span's (sum, M2) per row.
-// Lane layout: row = mrow0 + i*16 (mrow0 already includes lane & 15), columns nb + j*16 + fq*4 + r; the
-// four lanes fq = 0..3 of a row are lane, lane^16, lane^32, lane^48.
-template <int EPI, int MI, int NF, int MI_CH>
-__device__ __forceinline__ void gemm_epilogue_emit_tile(f32x4 (&acc)[MI][NF], const GemmArgs& p, int mrow0, int nb,
-                                                        int fq, int part) {
-    static_assert(EPI == EPI_RESID || EPI == EPI_F32, "fp32 outputs");
-    static_assert(MI % MI_CH == 0 && NF * 16 == 96, "96-column spans");
-    const float* __restrict__ resid = p.resid;
-    float* __restrict__ out = (float*)p.out;
-    bf16_t* __restrict__ ob = (bf16_t*)p.out_bf16;
-    int ncol[NF];
-    f32x4 bias[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int n = nb + j * 16 + fq * 4;
-        ncol[j] = n;
-        const int nc = min(n, p.N - 4);
-        bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int nvalid = max(0, min(96, p.stat_dim - nb));           // wave-uniform
-    const float inv_n = nvalid > 0 ? 1.0f / (float)nvalid : 0.f;
-#pragma unroll
-    for (int c = 0; c < MI; c += MI_CH) {
-        f32x4 v[MI_CH][NF];
-#pragma unroll
-        for (int ii = 0; ii < MI_CH; ++ii) {       // all loads of the chunk first (unconditional, clamped)
-            const int m = min(mrow0 + (c + ii) * 16, p.M - 1);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int nc = min(ncol[j], p.N - 4);
-                if constexpr (EPI == EPI_RESID) {
-                    v[ii][j] = *reinterpret_cast<const f32x4*>(resid + (size_t)m * p.ldo + nc);
-                } else {
-                    v[ii][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (p.rowbias && nc < p.rowbias_cols)
-                        v[ii][j] = *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m % p.rowbias_period) * p.rowbias_ld + nc);
-                }
-            }
-        }
-#pragma unroll
-        for (int ii = 0; ii < MI_CH; ++ii) {
-            const int m = mrow0 + (c + ii) * 16;
-            float s1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                if constexpr (EPI == EPI_RESID) v[ii][j] = v[ii][j] + p.alpha * (acc[c + ii][j] + bias[j]);
-                else v[ii][j] = v[ii][j] + acc[c + ii][j] + bias[j];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s1 += (ncol[j] + r < p.stat_dim) ? v[ii][j][r] : 0.f;
-            }
-            s1 += __shfl_xor(s1, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            const float mean = s1 * inv_n;
-            float s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = v[ii][j][r] - mean;
-                    s2 += (ncol[j] + r < p.stat_dim) ? d * d : 0.f;
-                }
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (m < p.M) {
-#pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    if (ncol[j] < p.N) {
-                        *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + ncol[j]) = v[ii][j];
-                        bf16x4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = f2bf(v[ii][j][r]);
-                        *reinterpret_cast<bf16x4*>(ob + (size_t)m * p.ld_bf16 + ncol[j]) = o;
-                    }
-                if (fq == 0) *reinterpret_cast<f32x2*>(p.stat_part + ((size_t)part * p.stat_stride + m) * 2) = f32x2{s1, s2};
             }
         }
     }

@@ -29,21 +29,6 @@ struct GemmArgs {
     int raster_gm;                   // 256-tile kernels: m-tiles per raster group (0 = choose by W size)
     int ksplit;                      // 256-tile kernels, EPI_F32 only: split K over ksplit workgroups per tile;
     size_t split_stride;             //   split s writes its partial product to out + s * split_stride (elements)
-    // ---- LayerNorm folded into the GEMMs around it (SigLIP blocks; DESIGN.md "LN fold") -----------
-    // y = LN(x) W^T + b  ==  rstd * (x (g.W)^T - mu * colsum) + (b + beta W^T):  the GEMM runs on the RAW
-    // bf16 rows of x with weights pre-scaled by gamma; mean / rstd are applied in the epilogue.
-    // Producer (256x192 kernel, EPI_RESID / EPI_F32): besides the fp32 output it writes bf16(out) and,
-    // per 96-column wave span, the row's (sum, centred sum of squares) over the fp32 values.
-    void* out_bf16; int ld_bf16;     // bf16 [M][ld_bf16] copy of the fp32 output, or null
-    float* stat_part;                // f32 [N/96][stat_stride][2], or null
-    int stat_dim;                    // true row width: columns >= stat_dim are padding (not counted)
-    // Consumer (EPI_BF16 / EPI_GELU): combines the partials of its rows (Chan's parallel variance) and
-    // computes out = rstd * acc - (mu * rstd) * ln_colsum[n] + bias[n].
-    const float* ln_part;            // f32 [ln_nparts][stat_stride][2], or null
-    int ln_nparts, ln_dim;           // parts per row (96 columns each), true row width
-    float ln_eps;
-    const float* ln_colsum;          // f32 [N] = sum_k Wfolded[n][k]
-    int stat_stride;                 // rows per part plane (both sides)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // 256x192 tile (gemm192.hip): N % 192 == 0, epilogues BF16 / GELU / F32 / RESID only
@@ -60,10 +45,6 @@ hipError_t launch_rmsnorm_accum(float* x, int rows, int dim, int ldx, const floa
                                 int ldo, hipStream_t s);
 hipError_t launch_rmsnorm(const float* x, int rows, int dim, int ldx, const float* w, float eps,
                           void* out, int ldo, hipStream_t s);
-// LN fold, weight side: Wf[n][k] = bf16(W[n][k] * gamma[k]) (0 for k >= K), colsum[n] = sum_k float(Wf[n][k]),
-// bias_f[n] = bias[n] + sum_k W[n][k] * beta[k].  W, Wf bf16 [rows][ldw]; one wave per row.
-hipError_t launch_ln_fold_weight(const void* W, int rows, int K, int ldw, const float* gamma, const float* beta,
-                                 const float* bias, void* Wf, float* colsum, float* bias_f, hipStream_t s);
 
 // ---- attention (attention.hip) -----------------------------------------------------------
 struct AttnArgs {

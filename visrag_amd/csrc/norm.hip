@@ -142,39 +142,4 @@ hipError_t launch_rmsnorm_accum(float* x, int rows, int dim, int ldx, const floa
     return hipGetLastError();
 }
 
-// ---- LN fold, weight side (once per checkpoint, vr_model_finalize) ---------------------------------
-// y = LN(x) W^T + b = rstd (x - mu) (gamma . W)^T + (b + beta W^T): fold gamma into the bf16 weight, keep
-// the column sums of the ROUNDED folded weight (so that the mean term cancels exactly what the MFMA sums)
-// and the beta term in the bias.  One wave per output row.
-__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const bf16_t* __restrict__ W, int rows, int K, int ldw,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ bias, bf16_t* __restrict__ Wf,
-                                                             float* __restrict__ colsum, float* __restrict__ bias_f) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= rows) return;
-    float cs = 0.f, bb = 0.f;
-    for (int k = lane; k < ldw; k += 64) {
-        bf16_t wf = (bf16_t)0.f;
-        if (k < K) {
-            const float w = bf2f(W[(size_t)n * ldw + k]);
-            wf = f2bf(w * gamma[k]);
-            bb += w * beta[k];
-        }
-        Wf[(size_t)n * ldw + k] = wf;
-        cs += bf2f(wf);
-    }
-    cs = wave_sum(cs);
-    bb = wave_sum(bb);
-    if (lane == 0) { colsum[n] = cs; bias_f[n] = (bias ? bias[n] : 0.f) + bb; }
-}
-
-hipError_t launch_ln_fold_weight(const void* W, int rows, int K, int ldw, const float* gamma, const float* beta,
-                                 const float* bias, void* Wf, float* colsum, float* bias_f, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ln_fold_weight_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16_t*)W, rows, K, ldw, gamma,
-                       beta, bias, (bf16_t*)Wf, colsum, bias_f);
-    return hipGetLastError();
-}
-
 }  // namespace vr
