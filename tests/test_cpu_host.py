@@ -171,3 +171,43 @@ def test_pil_resize_oracle_is_bit_exact():
         img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
         ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.Resampling.BICUBIC))
         assert np.array_equal(resize_bicubic(img, (ow, oh)), ref), ((h, w), (ow, oh))
+
+
+def test_checkpoint_config_and_iteration(tmp_path):
+    """config_from_checkpoint / iter_checkpoint (the loader half of DRModelForInference.build,
+    dense_retrieval_model.py:233-318): config.json fields, safetensors shards in sorted order, dtypes kept."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from visrag_amd.modeling import config_from_checkpoint, iter_checkpoint
+    d = tmp_path / "ckpt"; d.mkdir()
+    (d / "config.json").write_text(json.dumps({
+        "hidden_size": 2304, "num_hidden_layers": 40, "num_attention_heads": 36, "intermediate_size": 5760,
+        "vocab_size": 122753, "rms_norm_eps": 1e-5, "scale_emb": 12, "scale_depth": 1.4, "query_num": 64,
+        "patch_size": 14, "max_slice_nums": 9, "scale_resolution": 448, "slice_mode": False, "dim_model_base": 256}))
+    c = config_from_checkpoint(str(d))
+    assert (c.hidden_size, c.num_layers, c.num_heads, c.intermediate_size, c.vocab_size) == (2304, 40, 36, 5760, 122753)
+    assert c.slice_mode is False and c.scale_emb == 12 and abs(c.residual_scale - 1.4 / 40 ** 0.5) < 1e-12
+    save_file({"b.weight": torch.ones(2, 3, dtype=torch.float16), "a.weight": torch.zeros(4, dtype=torch.bfloat16)},
+              str(d / "model-00002-of-00002.safetensors"))
+    save_file({"c.bias": torch.arange(3, dtype=torch.float32)}, str(d / "model-00001-of-00002.safetensors"))
+    got = list(iter_checkpoint(str(d)))
+    assert [k for k, _ in got] == ["c.bias", "a.weight", "b.weight"]
+    assert [t.dtype for _, t in got] == [torch.float32, torch.bfloat16, torch.float16]
+    e = tmp_path / "empty"; e.mkdir()
+    with pytest.raises(FileNotFoundError):
+        list(iter_checkpoint(str(e)))
+
+
+def test_device_resolution(monkeypatch):
+    """build(device=None) follows LOCAL_RANK (torchrun) like the reference's encoding_args.device; explicit
+    cuda specs are parsed; non-cuda devices are refused (no CPU fallback)."""
+    import torch
+    from visrag_amd.modeling import _device_index, default_device
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert default_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert default_device() in (3, 3 % max(1, torch.cuda.device_count() or 4))
+    assert _device_index("cuda:2") == 2 and _device_index(5) == 5 and _device_index(torch.float16) is None
+    with pytest.raises(RuntimeError):
+        _device_index("cpu")

@@ -1,0 +1,125 @@
+"""-m gpu: BASELINE.json configs[0] END TO END at full MiniCPM-V-2.0 dimensions, through the drop-in entry
+points, against the fixture the REFERENCE produced (oracle/gen_golden.py --config1: 64 structured pages
+448x448 in batches of 16 + 16 text queries through openmatch's DRModelForInference on CPU fp32, then the
+reference's distributed_parallel_retrieve top-3):
+
+    distributed_parallel_embedding_inference (corpus, query)  ->  pickle shards
+    distributed_parallel_retrieve(args, 3)                     ->  {qid: {docid: score}}
+
+Bars (north_star): cosine >= 1 - 1e-3 for all 80 embeddings, every query x page score within 1e-3,
+IDENTICAL top-3 doc ids wherever the reference's rank-3 / rank-4 gap exceeds 2e-3 and
+tolerance-equivalent sets elsewhere.  Also: the decoder-side taps against the reference's hooks."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from visrag_amd import utils as U  # noqa: E402
+from visrag_amd.config import full_config  # noqa: E402
+from visrag_amd.inference import distributed_parallel_embedding_inference  # noqa: E402
+from visrag_amd.modeling import DRModelForInference  # noqa: E402
+from visrag_amd.retriever import distributed_parallel_retrieve  # noqa: E402
+from visrag_amd.synth import iter_synth_weights, synth_pages, synth_queries  # noqa: E402
+from visrag_amd.tokenizer import StandInTokenizer  # noqa: E402
+
+QUERY_PREFIX = "Represent this query for retrieving relevant documents: "
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    cfg = full_config()
+    model = DRModelForInference.build(cfg=cfg, state_dict=iter_synth_weights(cfg, 0, device="cuda"), max_images=32,
+                                      max_tokens=4096, max_seqs=64, pipeline=2)
+    yield cfg, model
+    for enc, _ in model._slots:
+        enc.close()
+
+
+@pytest.mark.parametrize("batch", [32, 16])
+def test_config1_encode_retrieve_top3(full_model, golden_dir, tmp_path, batch):
+    from PIL import Image
+    g = np.load(os.path.join(golden_dir, "config1_full.npz"))
+    n_pages, n_q, k = int(g["n_pages"]), int(g["n_queries"]), int(g["k"])
+    cfg, model = full_model
+    tok = StandInTokenizer(cfg.vocab_size)
+    pages = synth_pages(n_pages, size=448, seed=int(g["page_seed"]))
+    corpus = [{"id": f"doc{i}", "text": "", "image": Image.fromarray(p)} for i, p in enumerate(pages)]
+    queries = [{"id": f"q{i}", "text": QUERY_PREFIX + t, "image": None}
+               for i, t in enumerate(synth_queries(n_q, seed=int(g["query_seed"])))]
+    args = types.SimpleNamespace(output_dir=str(tmp_path), per_device_eval_batch_size=batch, process_index=0,
+                                 world_size=1, max_inmem_docs=batch, device=f"cuda:{model.encoder.device}")
+    extra = {"tokenizer": tok, "max_inp_length": 2048}
+    distributed_parallel_embedding_inference(corpus, model, args, "corpus", True, extra)      # 64 / batch shards
+    distributed_parallel_embedding_inference(queries, model, args, "query", False, {"tokenizer": tok, "max_inp_length": 512})
+    shards = U.list_shards(str(tmp_path), "corpus")
+    assert len(shards) == n_pages // batch
+    P = np.concatenate([U.read_shard(p)[0] for p in shards])
+    ids = [i for p in shards for i in U.read_shard(p)[1]]
+    Q, qids = U.read_shard(U.list_shards(str(tmp_path), "query", 0)[0])
+    assert ids == [f"doc{i}" for i in range(n_pages)] and qids == [f"q{i}" for i in range(n_q)]
+
+    # ---- embeddings and the whole score matrix vs the reference
+    assert ((P * g["p_reps"]).sum(1)).min() > 1 - TOL
+    assert ((Q * g["q_reps"]).sum(1)).min() > 1 - TOL
+    S = Q @ P.T
+    assert np.abs(S - g["scores"]).max() < TOL, np.abs(S - g["scores"]).max()
+
+    # ---- retrieval through the drop-in (reference semantics: union of per-shard top-k)
+    run = distributed_parallel_retrieve(args, k)
+    strict = 0
+    for qi in range(n_q):
+        got = sorted(run[f"q{qi}"].items(), key=lambda kv: (-kv[1], kv[0]))[:k]
+        ref_ids = [f"doc{j}" for j in g["top_ids"][qi, :k]]
+        for d, s in got:                                   # scores agree with the reference's
+            assert abs(s - g["scores"][qi, int(d[3:])]) < TOL
+        if g["gap"][qi] > 2 * TOL:                         # well separated: identical top-k doc ids, in order
+            strict += 1
+            assert [d for d, _ in got] == ref_ids, (qi, got, ref_ids, float(g["gap"][qi]))
+        else:                                              # near-tie at the cut: nothing outside the tolerance band
+            kth = g["top_scores"][qi, k - 1]
+            assert all(g["scores"][qi, int(d[3:])] >= kth - 2 * TOL for d, _ in got), (qi, got)
+    assert strict >= 5                                     # (the fixture has 7 well-separated queries)
+
+
+def test_decoder_taps_vs_reference(golden_dir):
+    """inputs to / inside the MiniCPM decoder against the reference's forward hooks at full dims
+    (tests/golden/full_encode.npz: page 0, every 4th token): the first decoder layer's output and the final
+    normed hidden states — a decoder-side regression must show here, not only in the final cosine."""
+    from PIL import Image
+    from visrag_amd.engine import HipEncoder
+    g = np.load(os.path.join(golden_dir, "full_encode.npz"))
+    cfg = full_config()
+    enc = HipEncoder(cfg, max_images=8, max_tokens=1024, max_seqs=8)
+    enc.load_state_dict(iter_synth_weights(cfg, 0, device="cuda"))
+    model = DRModelForInference(cfg, enc)
+    tok = StandInTokenizer(cfg.vocab_size)
+    pages = synth_pages(2, size=448, seed=0)
+    enc.set_taps(True)
+    model(passage={"id": ["0", "1"], "text": ["", ""], "image": [Image.fromarray(a) for a in pages]}, tokenizer=tok,
+          max_inp_length=2048)
+    L = 68
+    for name, tol in (("dec_layer0", 2e-2), ("last_hidden", 2e-2)):
+        got = enc.tap(name, L, cfg.hidden_size)[::4]
+        ref = g["tap_" + name]
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err < tol, (name, err)
+        # and direction-wise per token (robust to a few large coordinates)
+        cos = (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
+        assert cos.min() > 1 - 2e-3, (name, cos.min())
+    emb = enc.tap("inputs_embeds", L, cfg.hidden_size)
+    ids = g["page_input_ids"][0]
+    assert emb.shape == (L, cfg.hidden_size) and len(ids) == L
+    # token rows = embed_tokens * scale_emb (bf16 table): compare the non-image rows with the synthetic table
+    from visrag_amd.synth import synth_tensor, weight_specs
+    shape, amp, off = weight_specs(cfg)["llm.model.embed_tokens.weight"]
+    table = synth_tensor("llm.model.embed_tokens.weight", shape, amp, 0, off, device="cpu")
+    for t in (0, 1, L - 2, L - 1):                        # bos, <image>, </image>, "\n"
+        np.testing.assert_allclose(emb[t], table[int(ids[t])].float().numpy() * cfg.scale_emb, rtol=0, atol=1e-6)
+    enc.set_taps(False)
+    enc.close()

@@ -173,3 +173,57 @@ def test_full_dims_sliced_page_vs_oracle():
     ref = O.encode(W, cfg, [items[0].input_ids], [items[0].image_bound], [items[0].slices]).numpy()
     assert float((got * ref).sum()) > 1 - TOL
     enc.close()
+
+
+def test_build_from_checkpoint_dir(tmp_path):
+    """DRModelForInference.build(model_args) from a HF-style checkpoint directory (dense_retrieval_model.py:
+    233-318): sharded *.safetensors with bf16 AND fp16 tensors, keys the embedding path does not use
+    (llm.lm_head, vpm.attn_pool, the dropped last ViT block, rotary buffers), `pooling` / `normalize` from
+    model_args; embeddings equal the direct load of the same weights."""
+    import json
+    import types
+    from safetensors.torch import save_file
+    cfg = tiny_config()
+    sd = synth_state_dict(cfg, 0)
+    ck = tmp_path / "ckpt"; ck.mkdir()
+    (ck / "config.json").write_text(json.dumps({
+        "hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_layers, "num_attention_heads": cfg.num_heads,
+        "intermediate_size": cfg.intermediate_size, "vocab_size": cfg.vocab_size, "rms_norm_eps": cfg.rms_norm_eps,
+        "scale_emb": cfg.scale_emb, "scale_depth": cfg.scale_depth, "query_num": cfg.query_num,
+        "patch_size": cfg.patch_size, "max_slice_nums": cfg.max_slice_nums, "scale_resolution": cfg.scale_resolution,
+        "slice_mode": True}))
+    keys = list(sd)
+    half = len(keys) // 2
+    a = {k: sd[k].to(torch.bfloat16).contiguous() for k in keys[:half]}              # bf16 shard
+    b = {k: sd[k].to(torch.float16).contiguous() for k in keys[half:]}               # fp16 shard (eval.sh:66)
+    b["llm.lm_head.weight"] = torch.zeros((cfg.vocab_size, cfg.hidden_size), dtype=torch.float16)
+    b["vpm.attn_pool.latent"] = torch.zeros((1, 1, cfg.vit_dim), dtype=torch.float16)
+    b[f"vpm.blocks.{cfg.vit_depth}.norm1.weight"] = torch.ones(cfg.vit_dim, dtype=torch.float16)
+    b["llm.model.layers.0.self_attn.rotary_emb.inv_freq"] = torch.ones(32, dtype=torch.float32)
+    save_file(a, str(ck / "model-00001-of-00002.safetensors"))
+    save_file(b, str(ck / "model-00002-of-00002.safetensors"))
+    margs = types.SimpleNamespace(model_name_or_path=str(ck), pooling="wmean", normalize=True)
+    # (the ViT dims of a real checkpoint are fixed by its vision_encoder name; the tiny fixture passes them in)
+    model = DRModelForInference.build(model_args=margs, cfg=cfg, max_images=8, max_tokens=1024, max_seqs=8, pipeline=1)
+    assert model.to("cuda") is model and model.to(torch.device(f"cuda:{model.encoder.device}")) is model
+    with pytest.raises(RuntimeError):
+        model.to(f"cuda:{model.encoder.device + 1}")
+    tok = StandInTokenizer(cfg.vocab_size)
+    pages = _tiny_pages(cfg)[:3]
+    got = model(passage={"id": list("abc"), "text": [""] * 3, "image": [_pil(p) for p in pages]}, tokenizer=tok).p_reps.cpu().numpy()
+    ref_enc = HipEncoder(cfg, max_images=8, max_tokens=1024, max_seqs=8)
+    ref_enc.load_state_dict(sd.items())                       # CPU fp32 tensors, loaded directly
+    ref = DRModelForInference(cfg, ref_enc)(passage={"id": list("abc"), "text": [""] * 3, "image": [_pil(p) for p in pages]},
+                                            tokenizer=tok).p_reps.cpu().numpy()
+    # fp16 flushes the few synthetic values below 6e-8; everything else is exactly representable
+    assert ((got * ref).sum(1)).min() > 1 - 1e-5
+    # loading host weights again must not grow device memory (staging buffers are released: ADVICE r1)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(2):
+        ref_enc.load_state_dict(sd.items())
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < 8 << 20
+    with pytest.raises(ValueError):
+        DRModelForInference.build(model_args=types.SimpleNamespace(model_name_or_path=str(ck), pooling="mean"), cfg=cfg)
+    ref_enc.close(); model.encoder.close()

@@ -107,3 +107,52 @@ def test_two_batches_in_flight_give_the_same_embeddings():
         assert torch.equal(a, b)
     q = m(query={"text": ["what is shown"], "image": [None]}, tokenizer=tok).q_reps
     assert q.shape == (1, cfg.hidden_size) and bool(torch.isfinite(q).all())
+
+
+def test_demo_build_index_and_retrieve(tmp_path):
+    """visrag_amd.demo (drop-in for visrag_scripts/demo/visrag_pipeline/{build_index,answer,utils}.py): the
+    knowledge base files have the reference's layout, embeddings match the oracle, retrieve() returns the
+    oracle's ranking.  Page sizes are the tiny-model analogues of the reference's two demo images
+    (test_image/dog.jpg 1072x670 -> 2x2 slices, cat.jpeg 2160x1790 -> 3x3)."""
+    from PIL import Image
+    from visrag_amd import demo
+    cfg = tiny_config()
+    enc = HipEncoder(cfg, max_images=12, max_tokens=2048, max_seqs=16)
+    enc.load_state_dict(iter_synth_weights(cfg, 0, device="cuda"))
+    model = DRModelForInference(cfg, enc)
+    tok = StandInTokenizer(cfg.vocab_size)
+    big = synth_pages(2, size=560, seed=11)
+    pages = [Image.fromarray(p) for p in synth_pages(5, size=cfg.scale_resolution, seed=12)]
+    pages.append(Image.fromarray(np.ascontiguousarray(big[0][:168, :268])))     # 268x168 = (1072x670)/4 -> 2x2
+    pages.append(Image.fromarray(np.ascontiguousarray(big[1][:448, :540])))     # 540x448 = (2160x1790)/4 -> 3x3
+    from visrag_amd.preprocess import slice_image
+    assert slice_image(pages[5], cfg.max_slice_nums, cfg.scale_resolution, cfg.patch_size)[2] == [2, 2]
+    assert slice_image(pages[6], cfg.max_slice_nums, cfg.scale_resolution, cfg.patch_size)[2] == [3, 3]
+    kb = str(tmp_path / "kb")
+    reps = demo.add_pages(model, tok, pages, kb, names=[f"doc.pdf_{i}.png" for i in range(len(pages))], batch_size=3)
+    assert sorted(os.listdir(kb)) == sorted(["reps.npy", "index2img_filename.txt"] + [f"doc.pdf_{i}.png" for i in range(7)])
+    on_disk = np.load(os.path.join(kb, "reps.npy"))
+    assert on_disk.dtype == np.float32 and on_disk.shape == (7, cfg.hidden_size) and np.array_equal(on_disk, reps)
+    assert open(os.path.join(kb, "index2img_filename.txt")).read().split("\n") == [f"doc.pdf_{i}.png" for i in range(7)]
+    # oracle on the same pages / query
+    W = synth_state_dict(cfg, 0)
+    pit = prepare_batch([""] * 7, pages, tok, cfg, 2048)
+    P = O.encode(W, cfg, [i.input_ids for i in pit], [i.image_bound for i in pit], [i.slices for i in pit]).numpy()
+    assert ((P * reps).sum(1)).min() > 1 - 1e-3
+    query = "annual revenue growth chart"
+    qit = prepare_batch([demo.QUERY_INSTRUCTION + query], [None], tok, cfg, 2048)
+    Q = O.encode(W, cfg, [qit[0].input_ids], [[]], [[]]).numpy()
+    ref = (Q @ P.T)[0]
+    paths, scores = demo.retrieve(kb, query, 3, model, tok, return_scores=True)
+    assert len(paths) == 3 and all(os.path.exists(p) for p in paths)
+    order = np.argsort(-ref)
+    for p, s in zip(paths, scores):
+        i = int(os.path.basename(p).split("_")[1].split(".")[0])
+        assert abs(ref[i] - s) < 2.5e-3
+        assert ref[i] >= ref[order[2]] - 5e-3
+    if ref[order[2]] - ref[order[3]] > 5e-3:
+        assert [int(os.path.basename(p).split("_")[1].split(".")[0]) for p in paths] == list(order[:3])
+    ix, names = demo.load_knowledge_base(kb)
+    assert demo.retrieve(kb, query, 3, model, tok, index=ix, names=names) == paths
+    assert demo.retrieve(str(tmp_path / "missing"), query, 3, model, tok) is None
+    ix.close(); enc.close()
