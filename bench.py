@@ -51,17 +51,28 @@ def main():
     ap.add_argument("--pipelined", action="store_true",
                     help="also measure encode with two batches in flight (vr_model_clone + two HIP streams); "
                          "reported under \"pipelined\", never as `value`")
-    ap.add_argument("--cpu-pages", type=int, default=4)
+    ap.add_argument("--cpu-pages", type=int, default=16,
+                    help="pages of the CPU baseline sample (one reference-sized batch of 16 by default; 64 = all of "
+                         "BASELINE config 1, about 3 minutes of host time)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PIL-input and sliced-page measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = torch.distributed
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # one process per GPU (RCCL).  More ranks than visible GPUs (verifying the torchrun path on a 1-GPU box)
+    # share devices round-robin and rendezvous over gloo, because RCCL refuses two ranks on one device.
+    ndev = torch.cuda.device_count()
+    shared = world > ndev
+    local_rank %= ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
@@ -114,10 +125,13 @@ def main():
     dt = time.perf_counter() - t0
     prof = enc.get_profile()
     enc.set_profile(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def max_over_ranks(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if shared else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dt = max_over_ranks(dt)
     pages_per_s = world * args.steps * B / dt
     ms_per_step = dt / args.steps * 1e3
 
@@ -140,12 +154,9 @@ def main():
         for i in range(2 * args.steps):
             pstep(i)
         barrier()
-        dp = time.perf_counter() - tp
-        tmaxp = torch.tensor([dp], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tmaxp, op=dist.ReduceOp.MAX)
-        pipelined = {"in_flight": 2, "pages_per_sec": round(world * 2 * args.steps * B / float(tmaxp.item()), 2),
-                     "ms_per_step": round(float(tmaxp.item()) / (2 * args.steps) * 1e3, 3)}
+        dp = max_over_ranks(time.perf_counter() - tp)
+        pipelined = {"in_flight": 2, "pages_per_sec": round(world * 2 * args.steps * B / dp, 2),
+                     "ms_per_step": round(dp / (2 * args.steps) * 1e3, 3)}
         enc2.close()
 
     # ---- retrieval: fill the shard to index_rows/world rows with synthetic unit-norm embeddings,
@@ -177,11 +188,7 @@ def main():
     for _ in range(args.search_steps):
         sc, ids = sharded_search(index, Q, args.topk, id_offset=rank * rows_local)
     barrier()
-    ds = time.perf_counter() - ts0
-    tmax = torch.tensor([ds], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    ds = float(tmax.item())
+    ds = max_over_ranks(time.perf_counter() - ts0)
     search_qps = args.queries * args.search_steps / ds
     # event-timed local sweep (kernel time only, for the search roofline)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -212,10 +219,10 @@ def main():
     dom = max(gemm_like, key=lambda k: gemm_like[k]["ms"])
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    kernel_names = {"vit_qkv": "vr::gemm256_bf16_kernel<0, 4> (EPI_BF16; ViT qkv, 256x256 tile)",
-                    "vit_attn": "vr::attention_kernel<72, 2> (ViT self-attention)",
+    kernel_names = {"vit_qkv": "vr::gemm256_bf16_kernel<0> (EPI_BF16; ViT qkv, 256x256 tile)",
+                    "vit_attn": "vr::attention_kernel<72, 2, 3> (ViT self-attention, LDS-DMA staged)",
                     "vit_proj": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT attn proj, 256x192 tile)",
-                    "vit_fc1": "vr::gemm256_bf16_kernel<1, 4> (EPI_GELU; ViT MLP fc1, 256x256 tile, interleaved-read main loop)",
+                    "vit_fc1": "vr::gemm256_bf16_kernel<1> (EPI_GELU; ViT MLP fc1, 256x256 tile, interleaved-read main loop)",
                     "vit_fc2": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT MLP fc2, 256x192 tile)"}
     roofline = {"bound": "mfma", "kernel": kernel_names[dom], "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
@@ -267,7 +274,69 @@ def main():
         "pipelined": pipelined,
     }
 
-    # ---- CPU baseline: the oracle (fp32 restatement of the reference) on the host cores, rank 0, N=1
+    # ---- extras (outside `value`): what the reference's own entry point sees, and real-document pages
+    if world == 1 and not args.no_extras:
+        try:
+            import tempfile
+            import types
+            from visrag_amd.inference import distributed_parallel_embedding_inference
+            from visrag_amd.modeling import DRModelForInference
+            model = DRModelForInference(cfg, enc)
+            model.set_pipeline(2)
+            # (a) PIL pages in -> pickle shards out through distributed_parallel_embedding_inference: host
+            #     prompt/tokenise, H2D of the pixels, GPU resize (identity for 448x448), encode, D2H, pickle
+            n_pil = 8 * B
+            pil_pages = [Image.fromarray(pages[i % pool]) for i in range(n_pil)]
+            corpus = [{"id": str(i), "text": "", "image": im} for i, im in enumerate(pil_pages)]
+            with tempfile.TemporaryDirectory() as td:
+                a_ = types.SimpleNamespace(output_dir=td, per_device_eval_batch_size=B, process_index=0, world_size=1,
+                                           max_inmem_docs=10_000_000, device=str(dev))
+                distributed_parallel_embedding_inference(corpus[:2 * B], model, a_, "corpus", False,
+                                                         {"tokenizer": tok, "max_inp_length": 2048})
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                distributed_parallel_embedding_inference(corpus, model, a_, "corpus", False,
+                                                         {"tokenizer": tok, "max_inp_length": 2048})
+                torch.cuda.synchronize()
+                pil_s = time.perf_counter() - t0
+            result["pil_pipeline"] = {"pages_per_sec": round(n_pil / pil_s, 1), "pages": n_pil, "batch": B,
+                                      "what": "PIL images -> distributed_parallel_embedding_inference (host prepare + H2D + "
+                                              "encode, two batches in flight) -> one pickle shard"}
+            # (b) A4 pages rasterised at 200 dpi (1654x2339): 1 source + 3x3 slices of ~1026 patches, ~662 tokens
+            from visrag_amd.gpu_resize import prepare_item_gpu
+            a4 = np.ascontiguousarray(np.tile(pages[0], (6, 4, 1))[:2339, :1654])
+            a4_dev = torch.from_numpy(a4).to(dev)
+            nb = 8
+            its = [prepare_item_gpu("", a4_dev, tok, cfg, 2048, local_rank)[0] for _ in range(nb)]
+            n_sl, n_tok = len(its[0].slices), len(its[0].input_ids)
+            patches = sum((int(s_.shape[0]) // cfg.patch_size) * (int(s_.shape[1]) // cfg.patch_size) for s_ in its[0].slices)
+            f_a4 = sum(cfg.flops_vit((int(s_.shape[0]) // cfg.patch_size) * (int(s_.shape[1]) // cfg.patch_size)) +
+                       cfg.flops_resampler((int(s_.shape[0]) // cfg.patch_size) * (int(s_.shape[1]) // cfg.patch_size))
+                       for s_ in its[0].slices) + cfg.flops_decoder(n_tok)
+            for _ in range(2):
+                enc.encode_items(its)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                its = [prepare_item_gpu("", a4_dev, tok, cfg, 2048, local_rank)[0] for _ in range(nb)]   # GPU resize + slicing
+                enc.encode_items(its)
+            torch.cuda.synchronize()
+            a4_s = time.perf_counter() - t0
+            result["sliced_pages"] = {"pages_per_sec": round(4 * nb / a4_s, 2), "page": "A4 @ 200 dpi, 1654x2339",
+                                      "slices_per_page": n_sl, "patches_per_page": patches, "tokens_per_page": n_tok,
+                                      "tflop_per_page": round(f_a4 / 1e12, 2),
+                                      "model_tflops": round(4 * nb / a4_s * f_a4 / 1e12, 1),
+                                      "frac_of_mfma_peak": round(4 * nb / a4_s * f_a4 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                      "what": "device-resident page -> PIL-exact GPU bicubic resize + slicing -> encode, 8 pages per call"}
+            for e_, _s in model._slots[1:]:
+                e_.close()
+        except Exception as e:   # informational
+            result["extras_error"] = repr(e)
+
+    # ---- CPU baseline: the oracle (fp32 restatement of the reference) on the host cores, rank 0, N=1.
+    #      kind "port": /root/reference does not exist on the GPU box, so the timed code is oracle/ (pinned to
+    #      the reference by tests/test_oracle_golden.py).  The reference itself, timed in the build container by
+    #      the survey probe (8 cores): 0.52 pages/s, 1.8 queries/s (encode), 285 queries/s (retrieve 1k x 100k).
     if world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import visrag_ret_oracle as O
@@ -277,27 +346,39 @@ def main():
             tc = time.time()
             W = {k: v.cpu() for k, v in iter_synth_weights(cfg, 0, device=dev)}
             log(f"cpu weights in {time.time() - tc:.1f}s; threads={torch.get_num_threads()}")
-            n = args.cpu_pages
-            it = items[:n]
+            n, bs = args.cpu_pages, 16
+            it = (items * ((n + pool - 1) // pool))[:n]
             O.encode(W, cfg, [i.input_ids for i in it[:1]], [i.image_bound for i in it[:1]], [i.slices for i in it[:1]])
             tc = time.perf_counter()
-            ref = O.encode(W, cfg, [i.input_ids for i in it], [i.image_bound for i in it], [i.slices for i in it])
+            refs = [O.encode(W, cfg, [i.input_ids for i in it[lo:lo + bs]], [i.image_bound for i in it[lo:lo + bs]],
+                             [i.slices for i in it[lo:lo + bs]]) for lo in range(0, n, bs)]      # batches of 16 (README.md:146)
             cpu_s = time.perf_counter() - tc
-            got = enc.encode_items(it, device_slices=dev_pages[:n]).cpu()
+            ref = torch.cat(refs)
+            got = torch.cat([enc.encode_items(it[lo:lo + B], device_slices=(dev_pages * ((n + pool - 1) // pool))[lo:lo + B]).cpu()
+                             for lo in range(0, n, B)])
             cos = float((got * ref).sum(1).min())
-            # retrieval baseline: torch fp32 matmul + topk over the same index (dense_retriever.py:28-30)
-            Cc = torch.randn((20_000, cfg.hidden_size)); Cc = Cc / Cc.norm(dim=1, keepdim=True)
+            nq_cpu = 16
+            tc = time.perf_counter()
+            qref = O.encode(W, cfg, [i.input_ids for i in qitems[:nq_cpu]], [[]] * nq_cpu, [[]] * nq_cpu)
+            cpu_q_s = time.perf_counter() - tc
+            qcos = float((Q[:nq_cpu].cpu() * qref).sum(1).min())
+            # retrieval baseline: fp32 matmul + topk over the FULL index size (dense_retriever.py:28-30)
+            gC = torch.Generator().manual_seed(7)
+            Cc = torch.randn((args.index_rows, cfg.hidden_size), generator=gC); Cc = Cc / Cc.norm(dim=1, keepdim=True)
             Qc = Q.cpu()
             tc = time.perf_counter()
-            O.search_topk(Qc.numpy(), Cc.numpy(), args.topk)
+            torch.topk(torch.matmul(Qc, Cc.T), k=args.topk)        # the reference's two ops (dense_retriever.py:28-30)
             cpu_search_s = time.perf_counter() - tc
             result["cpu_baseline"] = {
                 "value": round(n / cpu_s, 3), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"{n} pages 448x448 through oracle/visrag_ret_oracle.py (torch-CPU fp32 restatement of the "
-                          f"reference forward, full dims) in {cpu_s:.1f}s; search: 1k queries x 20k rows fp32 "
-                          f"matmul+topk in {cpu_search_s:.2f}s",
-                "queries_per_sec_100k_est": round(args.queries / (cpu_search_s * args.index_rows / 20_000), 1),
-                "parity_min_cosine_vs_gpu": round(cos, 6)}
+                "sample": f"{n} pages 448x448 in batches of {bs} through oracle/visrag_ret_oracle.py (torch-CPU fp32 restatement "
+                          f"of the reference forward, full dims) in {cpu_s:.1f}s; {nq_cpu} text queries in {cpu_q_s:.1f}s; search: "
+                          f"{args.queries} queries x {args.index_rows} rows fp32 matmul+topk in {cpu_search_s:.2f}s (no extrapolation)",
+                "query_encode_per_sec": round(nq_cpu / cpu_q_s, 2),
+                "queries_per_sec_search": round(args.queries / cpu_search_s, 1),
+                "parity_min_cosine_vs_gpu": round(cos, 6), "parity_min_cosine_queries": round(qcos, 6),
+                "reference_in_build_container": {"pages_per_sec": 0.52, "query_encode_per_sec": 1.8, "queries_per_sec_search": 285,
+                                                 "cores": 8, "source": "BASELINE.md section 3 (survey probe of the reference's own code)"}}
         except Exception as e:   # the baseline is informational; never lose the GPU numbers
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(result), flush=True)
