@@ -306,9 +306,10 @@ def main():
             from visrag_amd.gpu_resize import prepare_item_gpu
             a4 = np.ascontiguousarray(np.tile(pages[0], (6, 4, 1))[:2339, :1654])
             a4_dev = torch.from_numpy(a4).to(dev)
-            nb = 8
+            one = prepare_item_gpu("", a4_dev, tok, cfg, 2048, local_rank)[0]
+            n_sl, n_tok = len(one.slices), len(one.input_ids)
+            nb = max(1, min(8, enc.max_tokens // n_tok))          # pages per call: the packed decoder tokens must fit
             its = [prepare_item_gpu("", a4_dev, tok, cfg, 2048, local_rank)[0] for _ in range(nb)]
-            n_sl, n_tok = len(its[0].slices), len(its[0].input_ids)
             patches = sum((int(s_.shape[0]) // cfg.patch_size) * (int(s_.shape[1]) // cfg.patch_size) for s_ in its[0].slices)
             f_a4 = sum(cfg.flops_vit((int(s_.shape[0]) // cfg.patch_size) * (int(s_.shape[1]) // cfg.patch_size)) +
                        cfg.flops_resampler((int(s_.shape[0]) // cfg.patch_size) * (int(s_.shape[1]) // cfg.patch_size))
@@ -327,7 +328,7 @@ def main():
                                       "tflop_per_page": round(f_a4 / 1e12, 2),
                                       "model_tflops": round(4 * nb / a4_s * f_a4 / 1e12, 1),
                                       "frac_of_mfma_peak": round(4 * nb / a4_s * f_a4 / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                      "what": "device-resident page -> PIL-exact GPU bicubic resize + slicing -> encode, 8 pages per call"}
+                                      "what": f"device-resident page -> PIL-exact GPU bicubic resize + slicing -> encode, {nb} pages per call"}
             for e_, _s in model._slots[1:]:
                 e_.close()
         except Exception as e:   # informational
@@ -354,8 +355,8 @@ def main():
                              [i.slices for i in it[lo:lo + bs]]) for lo in range(0, n, bs)]      # batches of 16 (README.md:146)
             cpu_s = time.perf_counter() - tc
             ref = torch.cat(refs)
-            got = torch.cat([enc.encode_items(it[lo:lo + B], device_slices=(dev_pages * ((n + pool - 1) // pool))[lo:lo + B]).cpu()
-                             for lo in range(0, n, B)])
+            dpx = (dev_pages * ((n + pool - 1) // pool))[:n]
+            got = torch.cat([enc.encode_items(it[lo:lo + B], device_slices=dpx[lo:lo + B]).cpu() for lo in range(0, n, B)])
             cos = float((got * ref).sum(1).min())
             nq_cpu = 16
             tc = time.perf_counter()
