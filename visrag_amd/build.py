@@ -21,8 +21,9 @@ SOURCES = ["gemm.hip", "gemm192.hip", "norm.hip", "attention.hip", "misc.hip", "
            "search_small.hip", "search_bigk.hip", "resize.hip", "pack.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: relaxed NaN handling only (infinities are honoured: masked scores are -inf).  Without it
-# every fmaxf of an MFMA result is preceded by a canonicalising v_max_f32 x, x (32 extra VALU per tile).
-FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
+# every fmaxf of an MFMA result is preceded by a canonicalising v_max_f32 x, x (32 extra VALU per tile);
+# same for the clamp of the GELU epilogue (gemm*.hip: one v_max per output value).
+FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nans"], "gemm192.hip": ["-fno-honor-nans"]}
 
 
 def lib_path(tag: str = "") -> str:

@@ -72,31 +72,28 @@ __global__ __launch_bounds__(512, 2) void gemm192_bf16_kernel(GemmArgs p) {
             return *reinterpret_cast<const bf16x8*>(t + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
         };
         const int arow = wm * 64 + fr, wrow = wn * 96 + fr;
-        bf16x8 w[6], wnx[6], a0, b0;
+        // (two A registers and one W set per K-half, all indices compile-time: no register copies)
+        bf16x8 w[2][6], a[2];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) w[j] = frag(tW, wrow + j * 16, 0);
-        a0 = frag(tA, arow, 0);
+        for (int j = 0; j < 6; ++j) w[0][j] = frag(tW, wrow + j * 16, 0);
+        a[0] = frag(tA, arow, 0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const int c = (kk * 4 + i) & 1, n = c ^ 1;
                 if (i < 3) {
-                    b0 = frag(tA, arow + (i + 1) * 16, kk);
+                    a[n] = frag(tA, arow + (i + 1) * 16, kk);
                 } else if (kk == 0) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) wnx[j] = frag(tW, wrow + j * 16, 1);
-                    b0 = frag(tA, arow, 1);
+                    for (int j = 0; j < 6; ++j) w[1][j] = frag(tW, wrow + j * 16, 1);
+                    a[n] = frag(tA, arow, 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 6; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a0, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kk][j], a[c], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                a0 = b0;
-                if (i == 3 && kk == 0) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) w[j] = wnx[j];
-                }
             }
         }
     }

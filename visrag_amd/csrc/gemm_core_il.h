@@ -8,7 +8,8 @@
 // that open the next K-half) are requested before the current group's MFMAs are issued: the reads
 // fly under ~140 cycles of matrix work, the wave never waits for more than its first six reads per
 // K-tile.  sched_barrier(0) pins the hand-written order; the compiler still inserts the counted
-// lgkmcnt waits.
+// lgkmcnt waits.  (The first reads of a K-tile are issued right after the stage barrier: the
+// previous tile's MFMAs have drained by then, their latency is the one exposed LDS round trip.)
 #pragma once
 #include "gemm_core.h"
 
@@ -16,6 +17,45 @@ namespace vr {
 
 __device__ __forceinline__ bf16x8 g256_frag(const char* t, int row, int kk, int fq) {
     return *reinterpret_cast<const bf16x8*>(t + row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4));
+}
+
+// the MFMAs of ONE K-step (64 wide) from a landed stage.  Two register sets for the A fragments (group G reads
+// set G & 1 while set (G + 1) & 1 is being filled) and one W set per K-half: every index is a compile-time
+// constant after unrolling, so there are NO register copies (the rotating a0 = b0 form of round 1 cost 128
+// v_mov per K-step and wave — a quarter of the loop's issue slots).
+__device__ __forceinline__ void gemm256_compute_il(gemm256_acc_t& acc, const char* tA, const char* tW, int arow,
+                                                   int wrow, int fq) {
+    bf16x8 w[2][4], a[2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[0][j] = g256_frag(tW, wrow + j * 16, 0, fq);
+    a[0][0] = g256_frag(tA, arow, 0, fq);
+    a[0][1] = g256_frag(tA, arow + 16, 0, fq);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cur = (kk * 4 + g) & 1, nxt = cur ^ 1;
+            // ---- request what the NEXT group needs
+            if (g < 3) {
+                a[nxt][0] = g256_frag(tA, arow + (2 * g + 2) * 16, kk, fq);
+                a[nxt][1] = g256_frag(tA, arow + (2 * g + 3) * 16, kk, fq);
+            } else if (kk == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[1][j] = g256_frag(tW, wrow + j * 16, 1, fq);
+                a[nxt][0] = g256_frag(tA, arow, 1, fq);
+                a[nxt][1] = g256_frag(tA, arow + 16, 1, fq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- 8 MFMAs of this group: strips 2g, 2g+1
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[2 * g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kk][j], a[cur][0], acc[2 * g][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[2 * g + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kk][j], a[cur][1], acc[2 * g + 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 __device__ __forceinline__ void gemm256_mainloop_il(gemm256_acc_t& acc, const bf16_t* __restrict__ A, int lda,
@@ -36,83 +76,9 @@ __device__ __forceinline__ void gemm256_mainloop_il(gemm256_acc_t& acc, const bf
             stage_glds(A, lda, m0, (kt + 1) * GEMM_BK, nxt, wave, lane);
             stage_glds(W, ldw, n0, (kt + 1) * GEMM_BK, nxt + G256_TILE_BYTES, wave, lane);
         }
-        const char* tA = cur;
-        const char* tW = cur + G256_TILE_BYTES;
-        bf16x8 w[4], a0, a1, wn_[4], b0, b1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = g256_frag(tW, wrow + j * 16, 0, fq);
-        a0 = g256_frag(tA, arow, 0, fq);
-        a1 = g256_frag(tA, arow + 16, 0, fq);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // ---- request what the NEXT group needs
-                if (g < 3) {
-                    b0 = g256_frag(tA, arow + (2 * g + 2) * 16, kk, fq);
-                    b1 = g256_frag(tA, arow + (2 * g + 3) * 16, kk, fq);
-                } else if (kk == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wn_[j] = g256_frag(tW, wrow + j * 16, 1, fq);
-                    b0 = g256_frag(tA, arow, 1, fq);
-                    b1 = g256_frag(tA, arow + 16, 1, fq);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- 8 MFMAs of this group: strips 2g, 2g+1
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[2 * g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a0, acc[2 * g][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[2 * g + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a1, acc[2 * g + 1][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                a0 = b0; a1 = b1;
-                if (g == 3 && kk == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = wn_[j];
-                }
-            }
-        }
+        gemm256_compute_il(acc, cur, cur + G256_TILE_BYTES, arow, wrow, fq);
     }
     __syncthreads();
-}
-
-// the MFMAs of ONE K-step (64 wide) from a landed stage, reads interleaved as above
-__device__ __forceinline__ void gemm256_compute_il(gemm256_acc_t& acc, const char* tA, const char* tW, int arow,
-                                                   int wrow, int fq) {
-    bf16x8 w[4], a0, a1, wx[4], b0, b1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = g256_frag(tW, wrow + j * 16, 0, fq);
-    a0 = g256_frag(tA, arow, 0, fq);
-    a1 = g256_frag(tA, arow + 16, 0, fq);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < 3) {
-                b0 = g256_frag(tA, arow + (2 * g + 2) * 16, kk, fq);
-                b1 = g256_frag(tA, arow + (2 * g + 3) * 16, kk, fq);
-            } else if (kk == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wx[j] = g256_frag(tW, wrow + j * 16, 1, fq);
-                b0 = g256_frag(tA, arow, 1, fq);
-                b1 = g256_frag(tA, arow + 16, 1, fq);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[2 * g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a0, acc[2 * g][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[2 * g + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a1, acc[2 * g + 1][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            a0 = b0; a1 = b1;
-            if (g == 3 && kk == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = wx[j];
-            }
-        }
-    }
 }
 
 }  // namespace vr

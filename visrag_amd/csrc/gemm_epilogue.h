@@ -6,31 +6,55 @@
 namespace vr {
 
 // nn.GELU() default = exact erf form (timm mlp.py / vision_transformer.py:466), NOT the tanh
-// approximation:  gelu(x) = 0.5 * (x + |x| * erf(|x| / sqrt2)).
-// The epilogue VALU work is not hidden by anything (one workgroup per CU: when its waves leave
-// the K-loop the matrix pipe idles), and for the fc1 GEMM (K = 1152, 18 K-steps) an erf with one
-// v_rcp + one v_exp per element (quarter-rate transcendentals: Abramowitz-Stegun 7.1.26, and far
-// worse libm erff) cost ~9 us per 256 x 256 tile against ~18 us of MFMA work.  Here erf is a pure
-// FMA chain that the compiler packs two elements per instruction (v_pk_fma_f32):
-//     erf(z) ~= z * P(z^2),  |z| <= 3   (degree-8 minimax-style fit, |err| <= 2.2e-5);   1 beyond
-// (1 - erf(3) = 2.2e-5).  |gelu error| <= 5.3e-5 absolute everywhere — an order of magnitude below
-// the bf16 rounding of the stored activation (half ulp >= 2.4e-4 for |y| >= 0.0625).
+// approximation:  gelu(x) = 0.5 * x * (1 + erf(x / sqrt2)).
+// The epilogue VALU work is not hidden by anything (one workgroup per CU: when its waves leave the K-loop the
+// matrix pipe idles).  PMC on the fc1 GEMM (K = 1152, 18 K-steps): a VALU instruction occupies its SIMD's
+// issue for 4 cycles, the 128 outputs per lane x 2 waves per SIMD of this epilogue came to ~20 % of the
+// tile's time with a compare / select / |x| formulation (11.5 VALU + 3 s_nop per value).  So: erf as an ODD
+// polynomial of the CLAMPED argument — no |x|, no compare, no select — in operations the compiler emits as
+// packed pairs (v_pk_fma_f32 / v_pk_mul_f32: two values per issue slot):
+//     xc = clamp(x, -X0, X0), X0 = 3 sqrt2;   erf(x / sqrt2) ~= xc * P(xc^2)   (1/sqrt2 folded into P)
+//     gelu = hx + hx * e,  hx = x / 2
+// 7 VALU slots per value.  |gelu error| <= 5e-5 for |x| <= 4.5 (degree-8 fit of erf, 2.2e-5) and
+// <= 1.1e-5 |x| beyond (the clamped erf stops at 0.99998 instead of 1) — below the bf16 rounding of the stored
+// activation wherever the output is not ~0, and ~1e-4 absolute on the zero side at |x| ~ 10.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float ax = fabsf(x);
-    const float z = ax * 0.70710678118654752440f;
-    const float zc = fminf(z, 3.0f);
-    const float t = zc * zc;
-    float p = 4.074216068e-08f;
-    p = fmaf(p, t, -1.944824664e-06f);
-    p = fmaf(p, t, 4.106055228e-05f);
-    p = fmaf(p, t, -5.110370805e-04f);
-    p = fmaf(p, t, 4.235428344e-03f);
-    p = fmaf(p, t, -2.510286350e-02f);
-    p = fmaf(p, t, 1.110793381e-01f);
-    p = fmaf(p, t, -3.753148771e-01f);
-    p = fmaf(p, t, 1.128268426e+00f);
-    const float e = (z >= 3.0f) ? 1.0f : zc * p;              // erf(|x| / sqrt2)
-    return 0.5f * fmaf(ax, e, x);
+    constexpr float X0 = 4.2426406871192851f;
+    const float xc = fminf(fmaxf(x, -X0), X0);
+    const float u = xc * xc;
+    float p = 1.125353832e-10f;
+    p = fmaf(p, u, -1.074373991e-08f);
+    p = fmaf(p, u, 4.536592962e-07f);
+    p = fmaf(p, u, -1.129243078e-05f);
+    p = fmaf(p, u, 1.871812565e-04f);
+    p = fmaf(p, u, -2.218800626e-03f);
+    p = fmaf(p, u, 1.963623831e-02f);
+    p = fmaf(p, u, -1.326938473e-01f);
+    p = fmaf(p, u, 7.978062550e-01f);
+    const float e = xc * p;                       // erf(x / sqrt2), saturating at +-0.99998
+    const float hx = 0.5f * x;
+    return fmaf(hx, e, hx);
+}
+// the same on four values at once: every Horner step is two independent packed FMAs, so consecutive steps
+// issue back to back (a lone dependent v_pk_fma_f32 chain needs a wait state between its links)
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 x) {
+    constexpr float X0 = 4.2426406871192851f;
+    const f32x4 lo = {-X0, -X0, -X0, -X0}, hi = {X0, X0, X0, X0};
+    const f32x4 xc = __builtin_elementwise_min(__builtin_elementwise_max(x, lo), hi);
+    const f32x4 u = xc * xc;
+    auto c4 = [](float c) { return f32x4{c, c, c, c}; };
+    f32x4 p = c4(1.125353832e-10f);
+    p = __builtin_elementwise_fma(p, u, c4(-1.074373991e-08f));
+    p = __builtin_elementwise_fma(p, u, c4(4.536592962e-07f));
+    p = __builtin_elementwise_fma(p, u, c4(-1.129243078e-05f));
+    p = __builtin_elementwise_fma(p, u, c4(1.871812565e-04f));
+    p = __builtin_elementwise_fma(p, u, c4(-2.218800626e-03f));
+    p = __builtin_elementwise_fma(p, u, c4(1.963623831e-02f));
+    p = __builtin_elementwise_fma(p, u, c4(-1.326938473e-01f));
+    p = __builtin_elementwise_fma(p, u, c4(7.978062550e-01f));
+    const f32x4 e = xc * p;
+    const f32x4 hx = x * c4(0.5f);
+    return __builtin_elementwise_fma(hx, e, hx);
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
@@ -89,9 +113,10 @@ __device__ __forceinline__ void gemm_epilogue_row(f32x4 (&acc)[NF], const GemmAr
             if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
             if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
             if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+                if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(EPI == EPI_GELU ? gelu_erf(v[r]) : v[r]);
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
                 *reinterpret_cast<bf16x4*>((bf16_t*)p.out + (size_t)orow * p.ldo + n) = o;
             } else if constexpr (EPI == EPI_F32) {
                 *reinterpret_cast<f32x4*>((float*)p.out + (size_t)orow * p.ldo + n) = v;
@@ -211,9 +236,10 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], cons
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
                 }
+                if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(EPI == EPI_GELU ? gelu_erf(v[r]) : v[r]);
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
                 const int c = j * 2 + (fq >> 1);               // 16-byte chunk of the 128-byte row
                 *reinterpret_cast<bf16x4*>(lrow + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
             }
