@@ -156,7 +156,7 @@ struct vr_model_s {
     std::map<std::pair<int, int>, GridTables> grids;
     // workspace
     int64_t Mcap = 0, Tcap = 0, Rcap = 0;     // padded rows: patches, tokens, resampler rows
-    DevBuf w_im2col, w_hvit, w_xn, w_qkv, w_att, w_mlp, w_kv32, w_xkv, w_KV, w_ratt, w_rout, w_rln;
+    DevBuf w_hvit, w_xn, w_qkv, w_att, w_mlp, w_kv32, w_xkv, w_KV, w_ratt, w_rout, w_rln;
     DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact, w_part;   // w_part: split-K partial products [3][T][E] f32
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
     std::map<std::string, Tap> taps;
@@ -270,7 +270,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     for (auto& pc : m->prof) for (hipEvent_t e : pc.ev) (void)hipEventDestroy(e);
     if (m->arena) (void)hipHostFree(m->arena);
     if (m->arena_ev) (void)hipEventDestroy(m->arena_ev);
-    for (DevBuf* b : {&m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
+    for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
                       &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
                       &m->w_pix, &m->w_out})
@@ -365,7 +365,12 @@ extern "C" int vr_model_load_weight(vr_model_t m, const char* name_c, const void
 
     if (name == "vpm.patch_embed.proj.weight") {
         if (!shape_is(shape, ndim, {D, 3, c.patch_size, c.patch_size})) return bad_shape();
-        return load_linear_part(m->patch, D, m->Kpe, src, bf, D, m->Kpe, 0, D, 0, 0);
+        Linear& L = m->patch;      // columns permuted to the image's byte order inside a patch (patch_embed.hip)
+        if (!L.w.p) { L.n = D; L.k = m->Kpe; L.n_pad = pad128(D); L.k_pad = pad128(m->Kpe); VRCHK(L.w.alloc((size_t)pad256(D) * L.k_pad * 2)); }
+        HIPCHK(launch_pack_patch_weight(src, bf, D, c.patch_size, L.w.p, L.k_pad, 0));
+        HIPCHK(hipDeviceSynchronize());
+        L.has_w = true;
+        return VR_OK;
     }
     if (name == "vpm.patch_embed.proj.bias") { if (numel != (size_t)D) return bad_shape(); return load_bias_part(m->patch, D, src, bf, D, 0); }
     if (name == "vpm.pos_embed") {
@@ -561,7 +566,6 @@ static int alloc_workspace(vr_model_s* m) {
     const int64_t R = pad256l((int64_t)c.max_images * m->Q);
     m->Mcap = M; m->Tcap = T; m->Rcap = R;
     const int E = m->E, Dp = m->Dp;
-    VRCHK(m->w_im2col.alloc((size_t)M * m->Kpe_p * 2));
     VRCHK(m->w_hvit.alloc((size_t)M * Dp * 4));
     VRCHK(m->w_xn.alloc((size_t)M * Dp * 2));
     VRCHK(m->w_qkv.alloc((size_t)M * pad128(3 * m->D) * 2));
@@ -775,12 +779,11 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     const int* cu_qry = m->w_cu.as<int>() + (n + 1);
 
     float* h = m->w_hvit.as<float>();
-    // K1+K2+K3: normalise + im2col, patch GEMM + bias + resampled pos-embed -> fp32 residual stream
-    HIPCHK(launch_im2col((const uint8_t* const*)m->w_imgptr.p, n, H, W, P, m->w_im2col.p, m->Kpe_p, s));
+    // K1+K2+K3: normalise + patch tiles built in LDS + conv-as-GEMM + bias + resampled pos-embed -> fp32 residual stream
     {
-        GemmArgs a = gemm_args(m->w_im2col.p, m->Kpe_p, m->patch, M, h, Dp);
+        GemmArgs a = gemm_args(nullptr, 0, m->patch, M, h, Dp);
         a.rowbias = g->vit_pos.as<float>(); a.rowbias_period = N; a.rowbias_ld = Dp; a.rowbias_cols = Dp;
-        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s));
+        HIPCHK(launch_patch_embed((const uint8_t* const*)m->w_imgptr.p, n, H, W, P, a, m->Kpe, s));
     }
     if (first_group) VRCHK(tap_store(m, "vit_embed", h, N, D, Dp, false, s));
     const int ldqkv = pad128(3 * D);
@@ -1053,7 +1056,7 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     VRCHK(set_dev(src->device));
     vr_model_s* m = new vr_model_s(*src);          // shallow: the weight buffers are aliased, never freed by the clone
     m->borrowed = true;
-    for (DevBuf* b : {&m->w_im2col, &m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
+    for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
                       &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out}) {
         b->free();                                 // (a non-owning alias after the copy: just forget it)

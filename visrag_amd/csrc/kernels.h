@@ -61,9 +61,10 @@ struct AttnArgs {
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
 // ---- elementwise / gather / pooling (misc.hip) ---------------------------------------------
-// u8 HWC image -> normalised bf16 im2col rows [(img, py, px)][c*P*P + ky*P + kx], K padded with 0.
-hipError_t launch_im2col(const uint8_t* const* imgs, int n_imgs, int H, int W, int P, void* out,
-                         int ldo, hipStream_t s);
+// Fused ToTensor/Normalize + patch-embed conv (patch_embed.hip): g carries the PERMUTED weight (k = ky*3P + kx*3 + c),
+// bias, the resampled pos-embed as rowbias (period = patches per image), out fp32 [M][ldo], M = n_imgs * patches.
+hipError_t launch_patch_embed(const uint8_t* const* imgs, int n_imgs, int H, int W, int P, const GemmArgs& g, int Kreal,
+                              hipStream_t s);
 // h[t][:] = table[ids[t]][:] * scale   (bf16 table -> f32 rows)
 hipError_t launch_embed_gather(const int* ids, int T, const void* table, int dim, float scale,
                                float* out, hipStream_t s);

@@ -1,42 +1,9 @@
-// HBM-bound glue kernels of the encode path: pixel normalisation + im2col, token-embedding
+// HBM-bound glue kernels of the encode path: token-embedding
 // gather, final RMSNorm + weighted-mean pool + L2 normalise, dtype conversions.
 #include "common.h"
 #include "kernels.h"
 
 namespace vr {
-
-// ---- K1+K2 front end: ToTensor + Normalize(0.5, 0.5) fused with the patch gather ------------
-// modeling_minicpmv.py:84-92 ((x/255 - 0.5)/0.5) and patch_embed.py:87 (Conv2d k=s=P as a GEMM
-// over rows [(img,py,px)] x columns [c*P*P + ky*P + kx], the flattening of weight [D,3,P,P]).
-__global__ __launch_bounds__(256) void im2col_kernel(const uint8_t* const* __restrict__ imgs, int H,
-                                                     int W, int P, bf16_t* __restrict__ out, int ldo) {
-    const int gw = W / P, gh = H / P;
-    const int prow = blockIdx.x;                      // patch row index over all images
-    const int img = prow / (gh * gw), pp = prow % (gh * gw);
-    const int py = pp / gw, px = pp % gw;
-    const uint8_t* src = imgs[img];
-    const int KK = 3 * P * P;
-    bf16_t* orow = out + (size_t)prow * ldo;
-    for (int k = threadIdx.x; k < ldo; k += 256) {
-        float v = 0.f;
-        if (k < KK) {
-            const int c = k / (P * P), rem = k % (P * P);
-            const int ky = rem / P, kx = rem % P;
-            const uint8_t u = src[((size_t)(py * P + ky) * W + (px * P + kx)) * 3 + c];
-            v = ((float)u / 255.0f - 0.5f) / 0.5f;
-        }
-        orow[k] = f2bf(v);
-    }
-}
-
-hipError_t launch_im2col(const uint8_t* const* imgs, int n_imgs, int H, int W, int P, void* out,
-                         int ldo, hipStream_t s) {
-    if (n_imgs <= 0) return hipSuccess;
-    if (H % P || W % P) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(im2col_kernel, dim3(n_imgs * (H / P) * (W / P)), dim3(256), 0, s, imgs, H, W, P,
-                       (bf16_t*)out, ldo);
-    return hipGetLastError();
-}
 
 // ---- K13: embed_tokens(ids) * scale_emb (modeling_minicpmv.py:139-141) ------------------------
 __global__ __launch_bounds__(256) void embed_gather_kernel(const int* __restrict__ ids, int T,

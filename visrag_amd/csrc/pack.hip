@@ -36,6 +36,27 @@ hipError_t launch_pack_weight(const void* src, int src_is_bf16, int rows, int co
 }
 
 template <typename SrcT>
+__global__ __launch_bounds__(256) void pack_patch_weight_kernel(const SrcT* __restrict__ src, int D, int P,
+                                                                bf16_t* __restrict__ dst, int dst_ld) {
+    const int K = 3 * P * P;
+    const size_t n = (size_t)D * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / K), k = (int)(i % K);          // k = c*P*P + ky*P + kx (conv weight order)
+        const int c = k / (P * P), ky = (k % (P * P)) / P, kx = k % P;
+        dst[(size_t)r * dst_ld + ky * 3 * P + kx * 3 + c] = f2bf((float)src[i]);
+    }
+}
+
+hipError_t launch_pack_patch_weight(const void* src, int src_is_bf16, int D, int P, void* dst, int dst_ld, hipStream_t s) {
+    const size_t n = (size_t)D * 3 * P * P;
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)min((size_t)4096, (n + 255) / 256);
+    if (src_is_bf16) hipLaunchKernelGGL(pack_patch_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, D, P, (bf16_t*)dst, dst_ld);
+    else hipLaunchKernelGGL(pack_patch_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, D, P, (bf16_t*)dst, dst_ld);
+    return hipGetLastError();
+}
+
+template <typename SrcT>
 __global__ void to_f32_kernel(const SrcT* __restrict__ src, float* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         dst[i] = (float)src[i];
