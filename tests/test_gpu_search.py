@@ -268,3 +268,28 @@ def test_retrieve_trec_equals_reference(golden_dir, tmp_path):
         assert abs(float(a[4]) - float(b[4])) < 1e-5, (a, b)
     top = distributed_parallel_retrieve(args, 5, global_topk=True)
     assert all(len(v) == 5 and set(v) <= set(run[q]) for q, v in top.items())
+
+
+def test_search_near_duplicate_cluster_is_tolerance_exact():
+    """What 'exact' means for the fused path: candidates are SELECTED by their bf16-MFMA scores
+    (the 16 best per query for k <= 10) and only those are re-scored in fp32.  With more near-duplicates than
+    candidates (64 copies of a page within 1e-4 of each other) the returned ids may be any of the copies whose
+    true score is within the bf16 dot-product error of the true k-th best — never a row outside the cluster,
+    and every returned score is the exact fp32 dot of its row."""
+    dim, nd, k = 2304, 20000, 10
+    C = _unit(nd, dim, 31)
+    q = _unit(1, dim, 32)
+    rng = np.random.default_rng(33)
+    base = q[0] + 0.5 * _unit(1, dim, 34)[0]
+    base /= np.linalg.norm(base)
+    cluster = np.arange(5000, 5064)
+    C[cluster] = base[None, :] + 1e-4 * rng.standard_normal((64, dim)).astype(np.float32)
+    C[cluster] /= np.linalg.norm(C[cluster], axis=1, keepdims=True)
+    ix = HipIndex(dim, nd); ix.add(C)
+    sc, ids = ix.search(q, k)
+    exact = (C.astype(np.float64) @ q[0].astype(np.float64))
+    kth = np.sort(exact)[-k]
+    assert set(ids[0].tolist()) <= set(cluster.tolist())                   # nothing from outside the cluster
+    np.testing.assert_allclose(sc[0], exact[ids[0]], atol=2e-6)            # scores are exact dots
+    assert (exact[ids[0]] >= kth - 1e-3).all(), (exact[ids[0]], kth)       # within the bf16 selection error of the true top-k
+    assert (np.diff(sc[0]) <= 0).all()
