@@ -1,6 +1,6 @@
 """A/B of GEMM variants on the model's shapes: gemm_ab.py v1 v2 ..."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tools.microbench import bench_gemm
 vs = [int(x) for x in sys.argv[1:]] or [9, 11]
 bench_gemm(8192, 8192, 8192, 0, 9)

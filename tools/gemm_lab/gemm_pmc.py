@@ -1,5 +1,5 @@
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tools.microbench import bench_gemm
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 if v != 99:

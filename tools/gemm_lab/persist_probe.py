@@ -1,7 +1,7 @@
 """Why is the persistent 256^2 GEMM (variant 10) +5 % alone but -20 % inside the model?  Time the GEMM with HIP events
 (a) back to back, (b) with its A operand rewritten by the LayerNorm kernel before every launch (as in a ViT block)."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests.gpu_util import P
 from visrag_amd import _lib
@@ -16,8 +16,12 @@ out = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
 s = torch.cuda.current_stream().cuda_stream
 def ln():
     _lib.check(lib.vr_op_norm(0, 0, P(x), M, K, P(w), P(b), 1e-6, P(A), K, s))
+import ctypes as C
+lab = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvisrag_gemm_lab.so")).vr_lab_gemm
+lab.restype = C.c_int; lab.argtypes = lib.vr_op_gemm.argtypes
 def gemm(v):
-    _lib.check(lib.vr_op_gemm(0, P(A), K, P(W), K, M, N, K, 0, P(bias), None, 1.0, P(out), N, None, None, 0, v, s))
+    f = lib.vr_op_gemm if v in (0, 3, 7, 9) else lab
+    _lib.check(f(0, P(A), K, P(W), K, M, N, K, 0, P(bias), None, 1.0, P(out), N, None, None, 0, v, s))
 ln(); torch.cuda.synchronize()
 for v in (9, 10):
     for mode in ("back-to-back", "after LayerNorm"):

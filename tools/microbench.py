@@ -53,9 +53,20 @@ def bench_gemm(M, N, K, epi=0, variant=0):
     resid = torch.zeros((M, ocols), dtype=torch.float32, device=dev) if epi == 3 else None
     s = torch.cuda.current_stream().cuda_stream
 
+    if variant in (0, 3, 7, 9):
+        call = lib.vr_op_gemm
+    else:           # round-1 experiment variants: tools/gemm_lab (python tools/gemm_lab/build.py)
+        import ctypes as C
+        lp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_lab", "libvisrag_gemm_lab.so")
+        if not os.path.exists(lp):
+            raise SystemExit(f"variant {variant} lives in the GEMM lab: build it with `python tools/gemm_lab/build.py`")
+        call = C.CDLL(lp).vr_lab_gemm
+        call.restype = C.c_int
+        call.argtypes = lib.vr_op_gemm.argtypes
+
     def fn():
-        _lib.check(lib.vr_op_gemm(0, P(A), K, P(Wt), K, M, N, K, epi, P(bias), P(resid), 1.0, P(out), ocols, None, None, 0,
-                                  variant, s))
+        _lib.check(call(0, P(A), K, P(Wt), K, M, N, K, epi, P(bias), P(resid), 1.0, P(out), ocols, None, None, 0,
+                        variant, s))
     ms = timeit(fn)
     return {"op": f"gemm M{M} N{N} K{K} epi{epi} v{variant}", "ms": round(ms, 4),
             "tflops": round(2.0 * M * N * K / ms / 1e9, 1)}
