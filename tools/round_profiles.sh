@@ -8,4 +8,5 @@ rocprofv3 --kernel-trace --stats -d /tmp/rp1 -o b -- python $R/bench.py --no-cpu
 python $R/tools/prof_summary.py $(find /tmp/rp1 -name '*.db' | head -1) $O/bench_kernel_trace.txt
 rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o e -- python $R/tools/encode_only.py 4 > /tmp/rp2.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/rp2 -name '*.db' | head -1) $O/encode_only_kernel_trace.txt
-tail -c 600 $O/bench_n1.json; head -12 $O/encode_only_kernel_trace.txt | cut -c1-140
+python $R/tools/search_bench.py 1000 128 16 1 > $O/search_bench.txt 2>/dev/null   # sweep TF/s and stream-kernel index GB/s
+tail -c 600 $O/bench_n1.json; cat $O/search_bench.txt; head -12 $O/encode_only_kernel_trace.txt | cut -c1-140
