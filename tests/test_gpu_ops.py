@@ -23,7 +23,7 @@ def _rand(shape, seed, scale=1.0):
 
 
 # ------------------------------------------------------------------------------- GEMM ---
-@pytest.mark.parametrize("variant", [0, 3, 9])
+@pytest.mark.parametrize("variant", [0, 3, 9, 12])
 @pytest.mark.parametrize("M,N,K", [(128, 256, 64), (300, 256, 192), (1024, 512, 640), (77, 256, 2304), (700, 768, 128)])
 def test_gemm_bias_bf16(M, N, K, variant):
     A, W, b = _bf(_rand((M, K), 1)), _bf(_rand((N, K), 2, 0.1)), _rand((N,), 3)
@@ -58,7 +58,7 @@ def test_gemm_identity_asymmetric():
     np.testing.assert_allclose(out.numpy(), _bf(W).float().T[:100].numpy(), rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 9])
+@pytest.mark.parametrize("variant", [0, 3, 9, 12])
 def test_gemm_epilogues(variant):
     M, N, K = 200, 256, 128
     A, W, b = _bf(_rand((M, K), 4)), _bf(_rand((N, K), 5, 0.2)), _rand((N,), 6)
@@ -83,7 +83,7 @@ def test_gemm_epilogues(variant):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 9])
+@pytest.mark.parametrize("variant", [0, 3, 9, 12])
 def test_gemm_rope(variant):
     """EPI_ROPE == apply_rotary_pos_emb (modeling_minicpm.py:259-290) on q,k columns; v untouched."""
     M, E, K = 150, 256, 128            # 4 heads of 64; N = 3E

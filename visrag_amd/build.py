@@ -17,13 +17,18 @@ from typing import Iterable, List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm192.hip", "norm.hip", "attention.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip",
+SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "norm.hip", "attention.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip",
            "search_small.hip", "search_bigk.hip", "resize.hip", "pack.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: relaxed NaN handling only (infinities are honoured: masked scores are -inf).  Without it
 # every fmaxf of an MFMA result is preceded by a canonicalising v_max_f32 x, x (32 extra VALU per tile);
 # same for the clamp of the GELU epilogue (gemm*.hip: one v_max per output value).
-FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nans"], "gemm192.hip": ["-fno-honor-nans"]}
+FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nans"], "gemm192.hip": ["-fno-honor-nans"],
+              "gemm256w.hip": ["-fno-honor-nans"]}
+# gemm256w.hip hand-allocates the accumulation registers inside asm statements; hipcc only sees them as clobbers,
+# so if it ever runs out of VGPRs there it parks the overflow in registers that hold results.  The build checks
+# the generated code: outside the kernel's own asm there must be no accumulation-register traffic at all.
+AGPR_CHECKED = {"gemm256w.hip"}
 
 
 def lib_path(tag: str = "") -> str:
@@ -44,6 +49,24 @@ def _newest_header() -> float:
             if f.endswith(".h"):
                 t = max(t, os.path.getmtime(os.path.join(d, f)))
     return t
+
+
+def _check_no_compiler_agprs(hipcc: str, src: str, flags: List[str]) -> None:
+    r = subprocess.run([hipcc, *[f for f in flags if f != "-fPIC"], "--cuda-device-only", "-S", src, "-o", "-"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr[-2000:]}")
+    in_asm = False
+    for ln in r.stdout.splitlines():
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif not in_asm and (t.startswith("v_accvgpr") or "scratch_" in t and "Spill" in t):
+            raise RuntimeError(f"{os.path.basename(src)}: hipcc generated `{t}` outside the hand-written asm — the "
+                               "accumulation registers are not the compiler's to use in this file (lower the VGPR "
+                               "pressure of the code around the K-loop)")
 
 
 def build(force: bool = False, verbose: bool = True, tag: str = "", defines: Optional[Iterable[str]] = None) -> str:
@@ -73,6 +96,8 @@ def build(force: bool = False, verbose: bool = True, tag: str = "", defines: Opt
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")
         if verbose and r.stderr.strip():
             sys.stderr.write(r.stderr)
+        if name in AGPR_CHECKED:
+            _check_no_compiler_agprs(hipcc, s, [*FLAGS, *FILE_FLAGS.get(name, []), *defines])
         return o
 
     if jobs:

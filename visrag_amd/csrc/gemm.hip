@@ -142,6 +142,7 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
+    if (variant == GEMM_VARIANT_256W) return launch_gemm256w(a, epi, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel
         if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID)

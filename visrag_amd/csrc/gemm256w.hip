@@ -1,0 +1,339 @@
+// 256 x 256 x 64 bf16 GEMM tile with ONE WAVE PER SIMD: 4 waves (2 x 2), 128 x 128 outputs per wave.
+//
+// Why: the 8-wave 256^2 kernel (gemm.hip) reads 12 fragments per 32 MFMAs and keeps two waves per
+// SIMD in lockstep behind one barrier per K-step; PMC puts its main loop at ~67 % matrix-pipe use
+// with the LDS ~75 % busy.  A 128 x 128 register tile reads 16 fragments per 64 MFMAs (a third less
+// LDS traffic per flop) and leaves the SIMD to a single wave whose instruction stream is laid out
+// by hand, so nothing has to be hidden by a second wave:
+//
+//   * the 256 fp32 accumulators of a lane live in the accumulation registers (a wave alone on its
+//     SIMD owns all 512 registers), the 32 operand fragments of a whole K-step in VGPRs;
+//   * software pipeline over K-steps (two LDS stages of A 32 KiB + W 32 KiB):
+//       phase 1: 64 MFMAs on the k-half-0 fragments; under them the 16 fragment reads of k-half 1,
+//                then `lgkmcnt(0) + barrier` (every wave has the whole stage in registers: the stage
+//                is free) and the 16 LDS-DMA loads of K-step kt+2 INTO THE STAGE BEING COMPUTED;
+//       phase 2: 64 MFMAs on the k-half-1 fragments; under them `vmcnt(16) + barrier` (K-step kt+1
+//                has landed; the 16 loads of kt+2 stay in flight) and the 16 k-half-0 fragment
+//                reads of K-step kt+1.
+//     Loads run two K-steps ahead with two LDS stages because the registers hold the step being
+//     computed; the MFMA stream never stops at a step boundary.
+//   * LDS-DMA through a buffer descriptor: per-lane offset in a VGPR (constant + K offset: two VALU
+//     adds per K-step), row-group offsets in SGPRs, the two K-steps past the end of K are pointed
+//     out of the descriptor's range (zeros written to the dead stage, no memory traffic), so every
+//     K-step runs the same code and the `vmcnt(16)` count always holds.
+//
+// LDS image, swizzle and epilogues are those of the 8-wave kernel (gemm_core.h, gemm_epilogue.h);
+// the accumulators are kept as two 64-column halves so the epilogue helpers apply unchanged.
+// Roofline: MFMA (2*M*N*K flops per launch).
+#include <type_traits>
+
+#include "gemm_core.h"
+#include "gemm_epilogue.h"
+
+namespace vr {
+
+namespace {
+
+constexpr int W_STAGE = 2 * G256_TILE_BYTES;       // A tile + W tile = 64 KiB
+constexpr unsigned W_OOB = 0x80000000u;            // per-lane offset beyond the descriptor's range
+
+// The 256 accumulators of a lane are HAND-ALLOCATED: accumulator n = strip * 8 + fragment (strip = 16-row
+// strip of the wave's 128 rows, fragment = 16-column fragment of its 128 columns) lives in a[4n : 4n+3].
+// hipcc cannot keep 64 four-register accumulators in a file they fill exactly: as builtin values, or as
+// "+a" asm operands, it rotates them through other registers around every MFMA (hundreds of v_accvgpr
+// moves and scratch spills per K-step), and with physical-register constraints it copies them in and out
+// of VGPRs around every statement.  So the MFMAs name their accumulation registers in the asm text, the
+// registers are zeroed and read back by asm as well, and the compiler only sees them as clobbers (which
+// also makes them count in the kernel's register allocation).  Its hazard bookkeeping does not see into
+// the asm: dependent MFMAs are 64 instructions apart, and explicit wait states separate the K-loop from
+// the read-back.  (The compiler never uses accumulation registers on its own here: no builtin MFMAs, and
+// the arch VGPRs do not spill.)
+#define W_FOR_EACH_ACC(X) \
+    X(0, "a[0:3]", "a0", "a1", "a2", "a3") \
+    X(1, "a[4:7]", "a4", "a5", "a6", "a7") \
+    X(2, "a[8:11]", "a8", "a9", "a10", "a11") \
+    X(3, "a[12:15]", "a12", "a13", "a14", "a15") \
+    X(4, "a[16:19]", "a16", "a17", "a18", "a19") \
+    X(5, "a[20:23]", "a20", "a21", "a22", "a23") \
+    X(6, "a[24:27]", "a24", "a25", "a26", "a27") \
+    X(7, "a[28:31]", "a28", "a29", "a30", "a31") \
+    X(8, "a[32:35]", "a32", "a33", "a34", "a35") \
+    X(9, "a[36:39]", "a36", "a37", "a38", "a39") \
+    X(10, "a[40:43]", "a40", "a41", "a42", "a43") \
+    X(11, "a[44:47]", "a44", "a45", "a46", "a47") \
+    X(12, "a[48:51]", "a48", "a49", "a50", "a51") \
+    X(13, "a[52:55]", "a52", "a53", "a54", "a55") \
+    X(14, "a[56:59]", "a56", "a57", "a58", "a59") \
+    X(15, "a[60:63]", "a60", "a61", "a62", "a63") \
+    X(16, "a[64:67]", "a64", "a65", "a66", "a67") \
+    X(17, "a[68:71]", "a68", "a69", "a70", "a71") \
+    X(18, "a[72:75]", "a72", "a73", "a74", "a75") \
+    X(19, "a[76:79]", "a76", "a77", "a78", "a79") \
+    X(20, "a[80:83]", "a80", "a81", "a82", "a83") \
+    X(21, "a[84:87]", "a84", "a85", "a86", "a87") \
+    X(22, "a[88:91]", "a88", "a89", "a90", "a91") \
+    X(23, "a[92:95]", "a92", "a93", "a94", "a95") \
+    X(24, "a[96:99]", "a96", "a97", "a98", "a99") \
+    X(25, "a[100:103]", "a100", "a101", "a102", "a103") \
+    X(26, "a[104:107]", "a104", "a105", "a106", "a107") \
+    X(27, "a[108:111]", "a108", "a109", "a110", "a111") \
+    X(28, "a[112:115]", "a112", "a113", "a114", "a115") \
+    X(29, "a[116:119]", "a116", "a117", "a118", "a119") \
+    X(30, "a[120:123]", "a120", "a121", "a122", "a123") \
+    X(31, "a[124:127]", "a124", "a125", "a126", "a127") \
+    X(32, "a[128:131]", "a128", "a129", "a130", "a131") \
+    X(33, "a[132:135]", "a132", "a133", "a134", "a135") \
+    X(34, "a[136:139]", "a136", "a137", "a138", "a139") \
+    X(35, "a[140:143]", "a140", "a141", "a142", "a143") \
+    X(36, "a[144:147]", "a144", "a145", "a146", "a147") \
+    X(37, "a[148:151]", "a148", "a149", "a150", "a151") \
+    X(38, "a[152:155]", "a152", "a153", "a154", "a155") \
+    X(39, "a[156:159]", "a156", "a157", "a158", "a159") \
+    X(40, "a[160:163]", "a160", "a161", "a162", "a163") \
+    X(41, "a[164:167]", "a164", "a165", "a166", "a167") \
+    X(42, "a[168:171]", "a168", "a169", "a170", "a171") \
+    X(43, "a[172:175]", "a172", "a173", "a174", "a175") \
+    X(44, "a[176:179]", "a176", "a177", "a178", "a179") \
+    X(45, "a[180:183]", "a180", "a181", "a182", "a183") \
+    X(46, "a[184:187]", "a184", "a185", "a186", "a187") \
+    X(47, "a[188:191]", "a188", "a189", "a190", "a191") \
+    X(48, "a[192:195]", "a192", "a193", "a194", "a195") \
+    X(49, "a[196:199]", "a196", "a197", "a198", "a199") \
+    X(50, "a[200:203]", "a200", "a201", "a202", "a203") \
+    X(51, "a[204:207]", "a204", "a205", "a206", "a207") \
+    X(52, "a[208:211]", "a208", "a209", "a210", "a211") \
+    X(53, "a[212:215]", "a212", "a213", "a214", "a215") \
+    X(54, "a[216:219]", "a216", "a217", "a218", "a219") \
+    X(55, "a[220:223]", "a220", "a221", "a222", "a223") \
+    X(56, "a[224:227]", "a224", "a225", "a226", "a227") \
+    X(57, "a[228:231]", "a228", "a229", "a230", "a231") \
+    X(58, "a[232:235]", "a232", "a233", "a234", "a235") \
+    X(59, "a[236:239]", "a236", "a237", "a238", "a239") \
+    X(60, "a[240:243]", "a240", "a241", "a242", "a243") \
+    X(61, "a[244:247]", "a244", "a245", "a246", "a247") \
+    X(62, "a[248:251]", "a248", "a249", "a250", "a251") \
+    X(63, "a[252:255]", "a252", "a253", "a254", "a255")
+#define W_MFMA(R, C0, C1, C2, C3, WV, AV) \
+    asm volatile("v_mfma_f32_16x16x32_bf16 " R ", %0, %1, " R : : "v"(WV), "v"(AV) : C0, C1, C2, C3)
+#define W_ZERO(n, R, C0, C1, C2, C3) \
+    asm volatile("v_accvgpr_write_b32 " C0 ", 0\n\tv_accvgpr_write_b32 " C1 ", 0\n\tv_accvgpr_write_b32 " C2 \
+                 ", 0\n\tv_accvgpr_write_b32 " C3 ", 0" : : : C0, C1, C2, C3);
+#define W_READ(V, C0, C1, C2, C3) \
+    asm volatile("v_accvgpr_read_b32 %0, " C0 "\n\tv_accvgpr_read_b32 %1, " C1 "\n\tv_accvgpr_read_b32 %2, " C2 \
+                 "\n\tv_accvgpr_read_b32 %3, " C3 : "=v"(V[0]), "=v"(V[1]), "=v"(V[2]), "=v"(V[3]))
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256w_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (p.N + G256_BN - 1) / G256_BN;
+    const int tiles_m = (p.M + G256_BM - 1) / G256_BM;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int tt = xcd_remap(blockIdx.x, tiles_m * tiles_n * ks);
+    const int split = tt / (tiles_m * tiles_n);
+    const int t = tt - split * (tiles_m * tiles_n);
+    // grouped rasterisation, as in gemm256_bf16_kernel
+    const int GM = p.raster_gm > 0 ? p.raster_gm : 1;
+    const int gsz = GM * tiles_n;
+    const int g = t / gsz, r = t % gsz;
+    const int gm = min(GM, tiles_m - g * GM);
+    const int m0 = __builtin_amdgcn_readfirstlane((g * GM + r % gm) * G256_BM);
+    const int n0 = __builtin_amdgcn_readfirstlane((r / gm) * G256_BN);
+
+#ifdef VR_W_TIMING                   // tile anatomy (tools/w_anatomy.py, tagged builds only): timestamps via rope_table
+    const unsigned long long tm0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tm1 = 0, tm2 = 0;
+#endif
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int Ks = p.K / ks;
+    const int nk = Ks / GEMM_BK;
+
+    // ---- LDS-DMA addressing: wave w fills rows [64 w, 64 w + 64) of both operand tiles, 8 rows per
+    //      instruction; lane l -> row l / 8, 16-byte chunk (l % 8) ^ (row % 8) of the 128-byte k-slice
+    const char* Ab = (const char*)p.A + ((size_t)m0 * p.lda + (size_t)split * Ks) * 2;
+    const char* Wb = (const char*)p.W + ((size_t)n0 * p.ldw + (size_t)split * Ks) * 2;
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7FFFFFFF, 0x00020000);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned lchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
+    const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
+    const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
+    const unsigned rgA = (unsigned)p.lda * 16u, rgW = (unsigned)p.ldw * 16u;      // bytes per 8-row group
+    const unsigned sA0 = (unsigned)wave * 8u * rgA, sW0 = (unsigned)wave * 8u * rgW;
+    char* const dmaA = smem + wave * 8192;
+    char* const dmaW = smem + G256_TILE_BYTES + wave * 8192;
+
+    // one of the 16 loads of a K-step: d < 8 -> A row group d, else W row group d - 8
+    auto dma = [&](int stage, int d, unsigned vA, unsigned vW) {
+        if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(dmaA + stage * W_STAGE + d * 1024), 16, vA, sA0 + d * rgA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(dmaW + stage * W_STAGE + (d - 8) * 1024), 16, vW, sW0 + (d - 8) * rgW, 0, 0);
+    };
+    auto kofs = [&](int kt) -> unsigned { return kt < nk ? (unsigned)kt * (GEMM_BK * 2) : W_OOB; };
+
+    // ---- fragment addressing: row = strip * 16 + fr, chunk (kk * 4 + fq) ^ (row & 7).  One LDS pointer per
+    //      (operand, stage, k-half) held in a VGPR; the strip is an immediate offset (strip * 2 KiB).
+    typedef const __attribute__((address_space(3))) bf16x8* frag_p;
+    frag_p pA[2][2], pW[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = ((kk * 4 + fq) ^ (fr & 7)) << 4;
+            pA[st][kk] = (frag_p)VR_LDS(smem + st * W_STAGE + (wm * 128 + fr) * 128 + ch);
+            pW[st][kk] = (frag_p)VR_LDS(smem + st * W_STAGE + G256_TILE_BYTES + (wn * 128 + fr) * 128 + ch);
+            asm volatile("" : "+v"(pA[st][kk]), "+v"(pW[st][kk]));
+        }
+
+    W_FOR_EACH_ACC(W_ZERO)
+
+    bf16x8 a0[8], w0[8], a1[8], w1[8];
+
+    // ---- prologue: K-steps 0 and 1 in flight, k-half-0 fragments of step 0 requested
+    {
+        const unsigned k0 = kofs(0), k1 = kofs(1);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) dma(0, d, lofA + k0, lofW + k0);
+#pragma unroll
+        for (int d = 0; d < 16; ++d) dma(1, d, lofA + k1, lofW + k1);
+        VR_WAIT_VM_BARRIER(16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w0[j] = pW[0][0][j * 128];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a0[i] = pA[0][0][i * 128];
+    }
+
+#ifdef VR_W_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tm1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    auto step = [&](auto stage_c, int kt) {
+        constexpr int S = decltype(stage_c)::value;
+        const unsigned k2 = kofs(kt + 2);
+        const unsigned vA = lofA + k2, vW = lofW + k2;
+        __builtin_amdgcn_sched_barrier(0);
+        // one auxiliary operation may follow each MFMA; n = position in the phase
+        auto aux1 = [&](int n) {
+            if (n < 32 && (n & 1) == 0) {
+                const int q = n >> 1;
+                if (q < 8) w1[q] = pW[S][1][q * 128];
+                else a1[q - 8] = pA[S][1][(q - 8) * 128];
+            }
+            if (n == 40) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (n > 40 && n <= 56) dma(S, n - 41, vA, vW);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto aux2 = [&](int n) {
+            if (n == 8) VR_WAIT_VM_BARRIER(16);
+            if (n >= 10 && n < 42 && (n & 1) == 0) {
+                const int q = (n - 10) >> 1;
+                if (q < 8) w0[q] = pW[S ^ 1][0][q * 128];
+                else a0[q - 8] = pA[S ^ 1][0][(q - 8) * 128];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // ---- phase 1: k-half 0, phase 2: k-half 1 (accumulator n: strip n / 8, fragment n % 8)
+#define W_P1(n, R, C0, C1, C2, C3) W_MFMA(R, C0, C1, C2, C3, w0[(n) & 7], a0[(n) >> 3]); aux1(n);
+#define W_P2(n, R, C0, C1, C2, C3) W_MFMA(R, C0, C1, C2, C3, w1[(n) & 7], a1[(n) >> 3]); aux2(n);
+        W_FOR_EACH_ACC(W_P1)
+        W_FOR_EACH_ACC(W_P2)
+#undef W_P1
+#undef W_P2
+    };
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 >= nk) break;
+        step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    VR_WAIT_VM_BARRIER(0);              // the out-of-range loads of the last two steps have written their zeros
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads (see w_mfma)
+
+#ifdef VR_W_TIMING
+    tm2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef VR_W_ABLATE_EPILOGUE          // timing experiments only (tagged builds): main loop without its epilogue
+    return;
+#endif
+    // ---- epilogue: in four pieces of 64 rows x 64 columns (64 accumulator registers read back into VGPRs at
+    //      a time; the scheduling barrier keeps hipcc from pulling the next piece's read-back up and running
+    //      out of VGPRs — it would park the overflow in accumulation registers that still hold results),
+    //      each exactly as the 128-tile kernel treats a wave tile
+    const int mrow0 = m0 + wm * 128, nb0 = n0 + wn * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        constexpr int MI = 4;
+        const int h = q & 1, sg = q >> 1;       // 64-column half, 64-row strip group
+        f32x4 acc[MI][4];                       // [16-row strip][16-column fragment]
+#define W_RD(n, R, C0, C1, C2, C3) \
+        if ((((n) & 7) >> 2) == h && ((n) >> 5) == sg) W_READ(acc[((n) >> 3) & 3][(n) & 3], C0, C1, C2, C3);
+        W_FOR_EACH_ACC(W_RD)
+#undef W_RD
+        const int mr = mrow0 + sg * 64, nb = nb0 + h * 64;
+        char* const wl = smem + wave * 32768 + q * 8192;
+        bool done = false;
+        if constexpr (EPI == EPI_F32) {
+            if (ks > 1) {
+                GemmArgs ps = p;
+                ps.out = (float*)p.out + (size_t)split * p.split_stride;
+                if (split > 0) ps.bias = nullptr;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI_F32>(acc[i], ps, mr + i * 16 + fr, nb, fq);
+                done = true;
+            }
+        }
+        if constexpr (EPI == EPI_RESID) {
+            if (!p.rowmap) { gemm_epilogue_resid_tile<MI, 4, 2>(acc, p, mr + fr, nb, fq); done = true; }
+        }
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
+            if ((p.N & 7) == 0 && (p.ldo & 7) == 0) { gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl); done = true; }
+        }
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI>(acc[i], p, mr + i * 16 + fr, nb, fq);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef VR_W_TIMING
+    if (threadIdx.x == 0 && p.rope_table) {
+        const unsigned long long tm3 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tm4 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* d = (unsigned long long*)p.rope_table + (size_t)blockIdx.x * 8;
+        d[0] = tm0; d[1] = tm1; d[2] = tm2; d[3] = tm3; d[4] = tm4;
+        d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
+        d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
+        d[7] = (unsigned long long)blockIdx.x;
+    }
+#endif
+}
+
+template <int EPI>
+static hipError_t launch_w(GemmArgs a, hipStream_t s) {
+    const int tn = (a.N + G256_BN - 1) / G256_BN, tm = (a.M + G256_BM - 1) / G256_BM;
+    if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
+    auto k = gemm256w_bf16_kernel<EPI>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr = true; }
+    int grid = tn * tm;
+    if (a.ksplit > 1) {
+        if (EPI != EPI_F32 || a.K % (a.ksplit * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
+        grid *= a.ksplit;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), G256_SMEM_BYTES, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BF16: return launch_w<EPI_BF16>(a, s);
+        case EPI_GELU: return launch_w<EPI_GELU>(a, s);
+        case EPI_F32: return launch_w<EPI_F32>(a, s);
+        case EPI_RESID: return launch_w<EPI_RESID>(a, s);
+        case EPI_SWIGLU: return launch_w<EPI_SWIGLU>(a, s);
+        case EPI_ROPE: return launch_w<EPI_ROPE>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace vr

@@ -190,8 +190,8 @@ namespace vr {
 // operand tiles, and reads it back row-wise: one store instruction = 8 rows x 128 B, full lines.
 //   wl: this wave's LDS slice, MI * 2 KiB (row pitch 128 B = 64 bf16; SwiGLU rows hold 32).
 template <int EPI, int MI>
-__device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], const GemmArgs& p, int mrow0, int nb,
-                                                       int lane, char* wl) {
+__device__ __forceinline__ void gemm_epilogue_tile_lds_general(f32x4 (&acc)[MI][4], const GemmArgs& p, int mrow0, int nb,
+                                                               int lane, char* wl) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE, "bf16 outputs only");
     const int fr = lane & 15, fq = lane >> 4;
     // ---- 1. fused math in registers, bf16 tile into LDS
@@ -271,6 +271,113 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], cons
             }
         }
     }
+}
+
+// The same for the GEMMs that have no per-row lookups (no row map, no row bias: every ViT / decoder GEMM of
+// the encode path).  In the general version each (strip, fragment) pair sits behind its own branches and
+// loads its bias again (the staging stores may alias it as far as hipcc can tell), so a wave walks a chain of
+// 32 dependent global-load round trips: in-kernel timestamps put the bf16 epilogue of a 256 x 256 tile at
+// 12.4 us even with four workgroups on an idle chip.  Here everything a lane needs from memory is requested
+// before the first use (bias: 4 loads per wave tile; RoPE: all positions, then the cos/sin rows two strips at
+// a time), the staging buffer is addressed as LDS, and the store loop has no loads at all.
+template <int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4], const GemmArgs& p, int mrow0, int nb,
+                                                             int lane, char* wl_generic) {
+    typedef __attribute__((address_space(3))) char* lds_p;
+    const lds_p wl = (lds_p)VR_LDS(wl_generic);
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = i * 16 + fr;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r]);
+                const int c = jj * 2 + (fq >> 1);
+                *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4) + (fq & 1) * 8) = o;
+            }
+        }
+    } else {
+        f32x4 bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bias[j] = *reinterpret_cast<const f32x4*>(p.bias + min(nb + j * 16 + fq * 4, p.N - 4));
+            }
+        }
+        if constexpr (EPI == EPI_ROPE) {
+            if (nb < p.rope_cols && nb < p.N) {        // (wave-uniform) this 64-column block is a q or k head
+                int pos[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) pos[i] = p.rope_pos[min(mrow0 + i * 16 + fr, p.M - 1)];
+#pragma unroll
+                for (int c = 0; c < MI; c += 2) {
+                    f32x4 cs[2][2], sn[2][2];
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const float* tab = p.rope_table + (size_t)pos[c + ii] * 64;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            cs[ii][j] = *reinterpret_cast<const f32x4*>(tab + j * 16 + fq * 4);
+                            sn[ii][j] = *reinterpret_cast<const f32x4*>(tab + 32 + j * 16 + fq * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 x1 = acc[c + ii][j], x2 = acc[c + ii][j + 2];
+                            acc[c + ii][j] = x1 * cs[ii][j] - x2 * sn[ii][j];
+                            acc[c + ii][j + 2] = x2 * cs[ii][j] + x1 * sn[ii][j];
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j] + bias[j];
+                if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                const int c = j * 2 + (fq >> 1);
+                *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+            }
+        }
+    }
+    // row-wise read-back (same wave: its LDS operations execute in order), full-line stores, no lookups
+    bf16_t* out = (bf16_t*)p.out;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int it = 0; it < MI; ++it) {
+            const int row = it * 16 + (lane >> 2), c = lane & 3;
+            const u32x4 d = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4));
+            const int m = mrow0 + row, n = nb / 2 + c * 8;
+            if (m < p.M && 2 * n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n) = d;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < MI * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), c = lane & 7;
+            const u32x4 d = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4));
+            const int m = mrow0 + row, n = nb + c * 8;
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n) = d;
+        }
+    }
+}
+
+template <int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue_tile_lds(f32x4 (&acc)[MI][4], const GemmArgs& p, int mrow0, int nb,
+                                                       int lane, char* wl) {
+    if (!p.rowmap && !p.rowbias) gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mrow0, nb, lane, wl);
+    else gemm_epilogue_tile_lds_general<EPI, MI>(acc, p, mrow0, nb, lane, wl);
 }
 
 }  // namespace vr
