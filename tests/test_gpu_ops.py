@@ -35,7 +35,7 @@ def test_gemm_bias_bf16(M, N, K, variant):
     assert (out - ref).abs().max() < 0.05 * ref.abs().max()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 192, 64), (1000, 1152, 320)])
+@pytest.mark.parametrize("M,N,K", [(300, 192, 64), (1000, 1152, 320), (520, 384, 4352)])
 def test_gemm_192_tile(M, N, K):
     """256x192 tile kernel (variant 7): bf16 / GELU / fp32 / residual epilogues."""
     A, W, b = _bf(_rand((M, K), 41)), _bf(_rand((N, K), 42, 0.1)), _rand((N,), 43)
@@ -45,8 +45,9 @@ def test_gemm_192_tile(M, N, K):
     np.testing.assert_allclose(op_gemm(Ad, Wd, 1, bias=bd, variant=7).float().cpu().numpy(),
                                torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=2e-2)
     r = _rand((M, N), 44)
-    out = op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.5, out_dtype=torch.float32, variant=7).cpu()
-    np.testing.assert_allclose(out.numpy(), (r + 0.5 * acc).numpy(), rtol=1e-5, atol=1e-4)
+    for variant in (7, 13):             # 13: the one-wave-per-SIMD form of the tile (residual epilogue only)
+        out = op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.5, out_dtype=torch.float32, variant=variant).cpu()
+        np.testing.assert_allclose(out.numpy(), (r + 0.5 * acc).numpy(), rtol=1e-5, atol=1e-4)
 
 
 def test_gemm_identity_asymmetric():

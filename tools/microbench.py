@@ -53,7 +53,7 @@ def bench_gemm(M, N, K, epi=0, variant=0):
     resid = torch.zeros((M, ocols), dtype=torch.float32, device=dev) if epi == 3 else None
     s = torch.cuda.current_stream().cuda_stream
 
-    if variant in (0, 3, 7, 9, 12):
+    if variant in (0, 3, 7, 9, 12, 13):
         call = lib.vr_op_gemm
     else:           # round-1 experiment variants: tools/gemm_lab (python tools/gemm_lab/build.py)
         import ctypes as C

@@ -58,7 +58,7 @@ for (M, N, K) in ((32768, 3456, 1152), (32768, 4352, 1152)):
         if v == "vendor":
             torch.matmul(A, Wt, out=out)
             return
-        f = lib.vr_op_gemm if v in (0, 3, 7, 9, 12) else lab
+        f = lib.vr_op_gemm if v in (0, 3, 7, 9, 12, 13) else lab
         _lib.check(f(0, P(A), K, P(W), K, M, N, K, 0, P(bias), None, 1.0, P(out), N, None, None, 0, v, s))
 
     ln(); torch.cuda.synchronize()

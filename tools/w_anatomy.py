@@ -21,7 +21,7 @@ for (M, N, K, epi) in shapes:
     bias = torch.randn(N, device="cuda")
     out = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
     tiles = (M // 256) * (Np // 256)
-    dbg = torch.zeros((tiles, 8), dtype=torch.int64, device="cuda")
+    dbg = torch.zeros((tiles, 16), dtype=torch.int64, device="cuda")
     for it in range(3):
         _lib.check(lib.vr_op_gemm(0, P(A), K, P(W), K, M, N, K, epi, P(bias), None, 1.0, P(out), N, None, P(dbg), 0, 12, s))
     torch.cuda.synchronize()
@@ -43,4 +43,6 @@ for (M, N, K, epi) in shapes:
                       "epilogue_issue_us": [round(float(np.median(epi_i)), 2), round(float(epi_i.max()), 2)],
                       "store_ack_us": [round(float(np.median(epi_w)), 2), round(float(epi_w.max()), 2)],
                       "gap_between_wgs_on_a_cu_us": [round(float(np.median(gaps)), 2), round(float(gaps.max()), 2)],
+                      "kloop_mhz": round(float(np.median(d[:, 7] / np.maximum(loop, 1e-3))), 0), "kstep_clocks": round(float(np.median(d[:, 7])) / (K // 64), 0),
+                      "per_kstep_clocks_wait_reads/barrier1/wait_dma/barrier2": [round(float(np.median(d[:, 8 + i])) / (K // 64), 0) for i in range(4)],
                       "first_start_spread_us": round(float(np.sort(t[:, 0])[min(255, tiles - 1)] - t0), 2)}))

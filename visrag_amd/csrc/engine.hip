@@ -1305,9 +1305,9 @@ extern "C" int vr_op_gemm(int device_id, const void* A, int32_t lda, const void*
                           int32_t ldo, const int32_t* rope_pos, const float* rope_table, int32_t rope_cols,
                           int32_t variant, void* stream) {
     if (!A || !W || !out) return fail(VR_ERR_INVALID, "NULL argument");
-    if (variant != GEMM_VARIANT_GLDS && variant != GEMM_VARIANT_AUTO && variant != GEMM_VARIANT_192 && variant != GEMM_VARIANT_256IL && variant != GEMM_VARIANT_256W)
-        return fail(VR_ERR_INVALID, "variant %d: 0 (128^2 tile), 3 (auto), 7 (256x192 tile), 9 (256^2 tile) or 12 (256^2 tile, one wave per SIMD)", variant);
-    if ((variant == 7 ? N % 192 : N % 128) || K % 64 || M <= 0) return fail(VR_ERR_INVALID, "need N %% 128 == 0 (192 for variant 7), K %% 64 == 0");
+    if (variant != GEMM_VARIANT_GLDS && variant != GEMM_VARIANT_AUTO && variant != GEMM_VARIANT_192 && variant != GEMM_VARIANT_256IL && variant != GEMM_VARIANT_256W && variant != GEMM_VARIANT_192W)
+        return fail(VR_ERR_INVALID, "variant %d: 0 (128^2 tile), 3 (auto), 7 (256x192 tile), 9 (256^2 tile), 12 / 13 (256^2 / 256x192 tile, one wave per SIMD)", variant);
+    if (((variant == 7 || variant == 13) ? N % 192 : N % 128) || K % 64 || M <= 0) return fail(VR_ERR_INVALID, "need N %% 128 == 0 (192 for variant 7), K %% 64 == 0");
     if (epilogue == EPI_RESID && !resid) return fail(VR_ERR_INVALID, "EPI_RESID needs resid");
     if (epilogue == EPI_ROPE && (!rope_pos || !rope_table)) return fail(VR_ERR_INVALID, "EPI_ROPE needs tables");
     VRCHK(set_dev(device_id));

@@ -143,21 +143,40 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_256W) return launch_gemm256w(a, epi, s);
+    if (variant == GEMM_VARIANT_192W) return launch_gemm192w(a, epi, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel
-        if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID)
+#ifndef VR_GEMM_AUTO_192W
+#define VR_GEMM_AUTO_192W 1
+#endif
+        if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID) {
+            if (VR_GEMM_AUTO_192W && epi == EPI_RESID && !a.rowmap) return launch_gemm192w(a, epi, s);
             return launch_gemm192(a, epi, s);
-        // 256x256 tiles when M is big enough to fill the chip with them and N is a multiple of 256
-        // or wide enough that one partial tile column costs little (3456 -> 14 tiles, +3.7 %);
-        // N = 1152 (4.5 tiles) stays on the 128x128 kernel (measured: 806 vs 771 TF).
-        // Small grids (decoder, M ~ 2k) are decided by wave quantisation: 256 one-per-CU slots for
-        // the big tile (~1.25x faster per flop) vs 512 two-per-CU slots for the small one.
+        }
+        // 256x256 tiles when N is a multiple of 256 or wide enough that one partial tile column costs
+        // little (3456 -> 14 tiles, +3.7 %); N = 1152 (4.5 tiles) goes to the 256x192 kernel above.
+        // Small grids (decoder, M ~ 2k) are decided by wave quantisation: 256 one-per-CU slots for the
+        // big tile vs 512 two-per-CU slots for the 128x128 one, whose flops cost ~1.45x the time and
+        // ~1.25x the energy of the one-wave-per-SIMD kernel's (tools/op_energy.py, decoder gate/up:
+        // 405 big tiles in two rounds 107 us / 134 mJ, 1530 small tiles in three rounds 121 us / 168 mJ).
         const bool n_ok = (a.N % 256 == 0) || a.N >= 2048;
         const long t256 = (long)((a.N + 255) / 256) * ((a.M + 255) / 256);
         const long t128 = (long)(a.N / 128) * ((a.M + 127) / 128);
-        const double e256 = 1.25 * (double)t256 / (double)(((t256 + 255) / 256) * 256);
+        const double e256 = 1.45 * (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        variant = (n_ok && e256 > e128) ? GEMM_VARIANT_256IL : GEMM_VARIANT_GLDS;
+#ifndef VR_GEMM_AUTO_W
+#define VR_GEMM_AUTO_W 0xFE
+#endif
+        // Which 256x256 kernel: the one-wave-per-SIMD kernel (gemm256w.hip) is faster and leaner everywhere in
+        // isolation (ViT qkv 230 vs 255 us, 302 vs 326 mJ), but its denser matrix-core stream pulls the
+        // shader clock down (1.9 vs 2.1 GHz sustained) and the clock recovers slowly: in the model the
+        // kernels that FOLLOW it run slower.  Measured in-model on one box (tools/ab_libs.sh, bit e of
+        // VR_GEMM_AUTO_W = epilogue e on the new kernel): fc1 (GELU) -0.75 ms/step, decoder GEMMs -0.2,
+        // ViT qkv +0.8 (attention, proj and the MLP behind it all slow down) — so plain-bf16 GEMMs with a
+        // ViT-sized M stay on the 8-wave kernel.
+        const bool w_ok = ((VR_GEMM_AUTO_W) >> epi) & 1 || (epi == EPI_BF16 && a.M < 16384);
+        variant = (n_ok && e256 > e128) ? (w_ok ? GEMM_VARIANT_256W : GEMM_VARIANT_256IL) : GEMM_VARIANT_GLDS;
+        if (variant == GEMM_VARIANT_256W) return launch_gemm256w(a, epi, s);
     }
     switch (epi) {
         case EPI_BF16: return launch_epi<EPI_BF16>(a, variant, s);

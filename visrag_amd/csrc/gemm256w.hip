@@ -11,16 +11,25 @@
 //   * software pipeline over K-steps (two LDS stages of A 32 KiB + W 32 KiB):
 //       phase 1: 64 MFMAs on the k-half-0 fragments; under them the 16 fragment reads of k-half 1,
 //                then `lgkmcnt(0) + barrier` (every wave has the whole stage in registers: the stage
-//                is free) and the 16 LDS-DMA loads of K-step kt+2 INTO THE STAGE BEING COMPUTED;
-//       phase 2: 64 MFMAs on the k-half-1 fragments; under them `vmcnt(16) + barrier` (K-step kt+1
-//                has landed; the 16 loads of kt+2 stay in flight) and the 16 k-half-0 fragment
-//                reads of K-step kt+1.
+//                is free) and the first LDS-DMA loads of K-step kt+2 INTO THE STAGE BEING COMPUTED;
+//       phase 2: 64 MFMAs on the k-half-1 fragments; under them `vmcnt(5) + barrier` (K-step kt+1
+//                has landed; the loads of kt+2 issued so far stay in flight), the rest of the loads
+//                of kt+2 and the 16 k-half-0 fragment reads of K-step kt+1.
 //     Loads run two K-steps ahead with two LDS stages because the registers hold the step being
 //     computed; the MFMA stream never stops at a step boundary.
+//   * the 16 LDS-DMA loads a wave issues per K-step are SPREAD, one per five MFMAs.  In-kernel clock
+//     counts per K-step (2048 = the 128 MFMAs alone): MFMAs + barriers 2100, + fragment reads 2094,
+//     + the 16 loads issued back to back 2777, + the same loads spread 2201.  The CU moves one 1 KiB
+//     LDS-DMA instruction per ~16 clocks; four waves issuing theirs in one burst queue behind each
+//     other and, being alone on their SIMDs, stall their MFMA streams while they wait.
 //   * LDS-DMA through a buffer descriptor: per-lane offset in a VGPR (constant + K offset: two VALU
 //     adds per K-step), row-group offsets in SGPRs, the two K-steps past the end of K are pointed
 //     out of the descriptor's range (zeros written to the dead stage, no memory traffic), so every
-//     K-step runs the same code and the `vmcnt(16)` count always holds.
+//     K-step runs the same code and the `vmcnt(5)` count always holds.
+//
+// NJ = 16-column fragments per wave: 8 -> 256 x 256 tile, 6 -> 256 x 192 tile (N = 1152 = 6 x 192: SigLIP proj / fc2,
+// residual epilogue only).  Slot s = strip * NJ + fragment numbers the MFMAs of a phase; the numbers in the
+// schedule above are those of NJ = 8, the NJ = 6 ones are scaled (see the constants in the kernel).
 //
 // LDS image, swizzle and epilogues are those of the 8-wave kernel (gemm_core.h, gemm_epilogue.h);
 // the accumulators are kept as two 64-column halves so the epilogue helpers apply unchanged.
@@ -124,10 +133,21 @@ constexpr unsigned W_OOB = 0x80000000u;            // per-lane offset beyond the
 
 }  // namespace
 
-template <int EPI>
+// PLAIN: the host has checked that the bf16-output epilogue needs no per-row lookups (no row map / row bias,
+// N and ldo multiples of 8) — the kernel then carries only the lookup-free staged epilogue.
+template <int EPI, bool PLAIN, int NJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256w_bf16_kernel(GemmArgs p) {
+    static_assert(NJ == 8 || (NJ == 6 && !PLAIN), "wave tile 128 x 128 or 128 x 96");
+    constexpr int BN = 32 * NJ;                 // tile columns
+    constexpr int NS = 8 * NJ;                  // MFMAs per phase (slots)
+    constexpr int NR = 8 + NJ;                  // fragment reads per k-half = LDS-DMA loads per K-step and wave
+    constexpr int DS = NJ == 8 ? 5 : 4;         // one load per DS slots
+    constexpr int SB1 = NS * 5 / 8;             // slot of the phase-1 barrier (the k-half-1 reads end at slot 2 NR - 2)
+    constexpr int D1 = (NS - 1 - (SB1 + 2)) / DS + 1;   // loads issued in phase 1 (slots SB1 + 2, + DS, ...)
+    constexpr int SB2 = NJ;                     // slot of the phase-2 barrier
+    static_assert(SB2 + 3 + DS * (NR - D1 - 1) < NS && SB2 + 2 + 2 * (NR - 1) < NS && 2 * NR - 2 < SB1, "schedule fits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_n = (p.N + G256_BN - 1) / G256_BN;
+    const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + G256_BM - 1) / G256_BM;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     const int tt = xcd_remap(blockIdx.x, tiles_m * tiles_n * ks);
@@ -139,11 +159,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int g = t / gsz, r = t % gsz;
     const int gm = min(GM, tiles_m - g * GM);
     const int m0 = __builtin_amdgcn_readfirstlane((g * GM + r % gm) * G256_BM);
-    const int n0 = __builtin_amdgcn_readfirstlane((r / gm) * G256_BN);
+    const int n0 = __builtin_amdgcn_readfirstlane((r / gm) * BN);
 
 #ifdef VR_W_TIMING                   // tile anatomy (tools/w_anatomy.py, tagged builds only): timestamps via rope_table
     const unsigned long long tm0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long tm1 = 0, tm2 = 0;
+    unsigned cyc_b1w = 0, cyc_b1 = 0, cyc_b2w = 0, cyc_b2 = 0;     // shader clocks in the two waits / barriers of a K-step
 #endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
@@ -160,11 +181,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
     const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
     const unsigned rgA = (unsigned)p.lda * 16u, rgW = (unsigned)p.ldw * 16u;      // bytes per 8-row group
-    const unsigned sA0 = (unsigned)wave * 8u * rgA, sW0 = (unsigned)wave * 8u * rgW;
+    const unsigned sA0 = (unsigned)wave * 8u * rgA, sW0 = (unsigned)wave * (unsigned)NJ * rgW;
     char* const dmaA = smem + wave * 8192;
-    char* const dmaW = smem + G256_TILE_BYTES + wave * 8192;
+    char* const dmaW = smem + G256_TILE_BYTES + wave * (NJ * 1024);
 
-    // one of the 16 loads of a K-step: d < 8 -> A row group d, else W row group d - 8
+    // one of the NR loads of a K-step: d < 8 -> A row group d, else W row group d - 8 (W rows [8 NJ w, 8 NJ (w + 1)))
     auto dma = [&](int stage, int d, unsigned vA, unsigned vW) {
         if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(dmaA + stage * W_STAGE + d * 1024), 16, vA, sA0 + d * rgA, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(dmaW + stage * W_STAGE + (d - 8) * 1024), 16, vW, sW0 + (d - 8) * rgW, 0, 0);
@@ -181,24 +202,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int kk = 0; kk < 2; ++kk) {
             const int ch = ((kk * 4 + fq) ^ (fr & 7)) << 4;
             pA[st][kk] = (frag_p)VR_LDS(smem + st * W_STAGE + (wm * 128 + fr) * 128 + ch);
-            pW[st][kk] = (frag_p)VR_LDS(smem + st * W_STAGE + G256_TILE_BYTES + (wn * 128 + fr) * 128 + ch);
+            pW[st][kk] = (frag_p)VR_LDS(smem + st * W_STAGE + G256_TILE_BYTES + (wn * 16 * NJ + fr) * 128 + ch);
             asm volatile("" : "+v"(pA[st][kk]), "+v"(pW[st][kk]));
         }
 
     W_FOR_EACH_ACC(W_ZERO)
 
-    bf16x8 a0[8], w0[8], a1[8], w1[8];
+    bf16x8 a0[8], w0[NJ], a1[8], w1[NJ];
 
     // ---- prologue: K-steps 0 and 1 in flight, k-half-0 fragments of step 0 requested
     {
         const unsigned k0 = kofs(0), k1 = kofs(1);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) dma(0, d, lofA + k0, lofW + k0);
+        for (int d = 0; d < NR; ++d) dma(0, d, lofA + k0, lofW + k0);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) dma(1, d, lofA + k1, lofW + k1);
-        VR_WAIT_VM_BARRIER(16);
+        for (int d = 0; d < NR; ++d) dma(1, d, lofA + k1, lofW + k1);
+        if constexpr (NJ == 8) VR_WAIT_VM_BARRIER(16); else VR_WAIT_VM_BARRIER(14);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w0[j] = pW[0][0][j * 128];
+        for (int j = 0; j < NJ; ++j) w0[j] = pW[0][0][j * 128];
 #pragma unroll
         for (int i = 0; i < 8; ++i) a0[i] = pA[0][0][i * 128];
     }
@@ -206,35 +227,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef VR_W_TIMING
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     tm1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long cy1 = __builtin_amdgcn_s_memtime();
 #endif
     auto step = [&](auto stage_c, int kt) {
         constexpr int S = decltype(stage_c)::value;
         const unsigned k2 = kofs(kt + 2);
         const unsigned vA = lofA + k2, vW = lofW + k2;
         __builtin_amdgcn_sched_barrier(0);
-        // one auxiliary operation may follow each MFMA; n = position in the phase
-        auto aux1 = [&](int n) {
-            if (n < 32 && (n & 1) == 0) {
-                const int q = n >> 1;
-                if (q < 8) w1[q] = pW[S][1][q * 128];
-                else a1[q - 8] = pA[S][1][(q - 8) * 128];
+        // one auxiliary operation may follow each MFMA; sl = its slot in the phase
+        auto aux1 = [&](int sl) {
+            if (sl < 2 * NR && (sl & 1) == 0) {
+                const int q = sl >> 1;
+                if (q < NJ) w1[q] = pW[S][1][q * 128];
+                else a1[q - NJ] = pA[S][1][(q - NJ) * 128];
             }
-            if (n == 40) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (n > 40 && n <= 56) dma(S, n - 41, vA, vW);
+            if (sl == SB1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (sl >= SB1 + 2 && (sl - (SB1 + 2)) % DS == 0) dma(S, (sl - (SB1 + 2)) / DS, vA, vW);     // loads 0 .. D1-1
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto aux2 = [&](int n) {
-            if (n == 8) VR_WAIT_VM_BARRIER(16);
-            if (n >= 10 && n < 42 && (n & 1) == 0) {
-                const int q = (n - 10) >> 1;
-                if (q < 8) w0[q] = pW[S ^ 1][0][q * 128];
-                else a0[q - 8] = pA[S ^ 1][0][(q - 8) * 128];
+        auto aux2 = [&](int sl) {
+            if (sl == SB2) { if constexpr (D1 == 5) VR_WAIT_VM_BARRIER(5); else VR_WAIT_VM_BARRIER(4); }
+            if (sl >= SB2 + 3 && (sl - (SB2 + 3)) % DS == 0 && D1 + (sl - (SB2 + 3)) / DS < NR)
+                dma(S, D1 + (sl - (SB2 + 3)) / DS, vA, vW);                                              // loads D1 .. NR-1
+            if (sl >= SB2 + 2 && sl < SB2 + 2 + 2 * NR && ((sl - SB2) & 1) == 0) {
+                const int q = (sl - (SB2 + 2)) >> 1;
+                if (q < NJ) w0[q] = pW[S ^ 1][0][q * 128];
+                else a0[q - NJ] = pA[S ^ 1][0][(q - NJ) * 128];
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        // ---- phase 1: k-half 0, phase 2: k-half 1 (accumulator n: strip n / 8, fragment n % 8)
-#define W_P1(n, R, C0, C1, C2, C3) W_MFMA(R, C0, C1, C2, C3, w0[(n) & 7], a0[(n) >> 3]); aux1(n);
-#define W_P2(n, R, C0, C1, C2, C3) W_MFMA(R, C0, C1, C2, C3, w1[(n) & 7], a1[(n) >> 3]); aux2(n);
+        // ---- phase 1: k-half 0, phase 2: k-half 1 (accumulator n: strip n / 8, fragment n % 8 < NJ)
+#define W_P1(n, R, C0, C1, C2, C3) \
+        if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w0[(n) & 7], a0[(n) >> 3]); aux1(((n) >> 3) * NJ + ((n) & 7)); }
+#define W_P2(n, R, C0, C1, C2, C3) \
+        if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w1[(n) & 7], a1[(n) >> 3]); aux2(((n) >> 3) * NJ + ((n) & 7)); }
         W_FOR_EACH_ACC(W_P1)
         W_FOR_EACH_ACC(W_P2)
 #undef W_P1
@@ -251,6 +277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #ifdef VR_W_TIMING
     tm2 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long cy2 = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef VR_W_ABLATE_EPILOGUE          // timing experiments only (tagged builds): main loop without its epilogue
     return;
@@ -259,17 +286,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //      a time; the scheduling barrier keeps hipcc from pulling the next piece's read-back up and running
     //      out of VGPRs — it would park the overflow in accumulation registers that still hold results),
     //      each exactly as the 128-tile kernel treats a wave tile
-    const int mrow0 = m0 + wm * 128, nb0 = n0 + wn * 128;
+    const int mrow0 = m0 + wm * 128, nb0 = n0 + wn * (16 * NJ);
+    constexpr int NF = NJ / 2;                  // fragments per piece: 64 or 48 columns
+    if constexpr (EPI == EPI_RESID) {
+        // out = resid + alpha * (acc + bias), fp32, in place: the residual of piece q + 1 is requested before piece
+        // q is combined and stored, so (one wave per SIMD, nothing else to hide it) only the first piece's load
+        // latency is exposed.  Addresses are clamped for rows >= M / columns >= N, the stores are predicated.
+        if (!p.rowmap) {
+            constexpr int MI = 2;               // pieces of 32 rows x 16 NF columns: 8 per wave
+            const float* __restrict__ resid = p.resid;
+            float* __restrict__ out = (float*)p.out;
+            f32x4 rs[2][MI][NF];
+            auto load_piece = [&](int q, f32x4 (&dst)[MI][NF]) {
+                const int h = q & 1, sg = q >> 1;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const size_t ro = (size_t)min(mrow0 + (sg * MI + i) * 16 + fr, p.M - 1) * p.ldo;
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        dst[i][j] = *reinterpret_cast<const f32x4*>(resid + ro + min(nb0 + (h * NF + j) * 16 + fq * 4, p.N - 4));
+                }
+            };
+            load_piece(0, rs[0]);
+            f32x4 bias[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(nb0 + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int h = q & 1, sg = q >> 1;
+                if (q < 7) load_piece(q + 1, rs[(q + 1) & 1]);
+                f32x4 acc[MI][NF];
+#define W_RD(n, R, C0, C1, C2, C3) \
+                if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
+                W_FOR_EACH_ACC(W_RD)
+#undef W_RD
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = mrow0 + (sg * MI + i) * 16 + fr;
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        const int n = nb0 + (h * NF + j) * 16 + fq * 4;
+                        if (m < p.M && n < p.N)
+                            *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q & 1][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifdef VR_W_TIMING
+            goto timing_tail;
+#else
+            return;
+#endif
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         constexpr int MI = 4;
-        const int h = q & 1, sg = q >> 1;       // 64-column half, 64-row strip group
-        f32x4 acc[MI][4];                       // [16-row strip][16-column fragment]
+        const int h = q & 1, sg = q >> 1;       // column half, 64-row strip group
+        f32x4 acc[MI][NF];                      // [16-row strip][16-column fragment]
 #define W_RD(n, R, C0, C1, C2, C3) \
-        if ((((n) & 7) >> 2) == h && ((n) >> 5) == sg) W_READ(acc[((n) >> 3) & 3][(n) & 3], C0, C1, C2, C3);
+        if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 5) == sg) W_READ(acc[((n) >> 3) & 3][((n) & 7) % NF], C0, C1, C2, C3);
         W_FOR_EACH_ACC(W_RD)
 #undef W_RD
-        const int mr = mrow0 + sg * 64, nb = nb0 + h * 64;
+        const int mr = mrow0 + sg * 64, nb = nb0 + h * (16 * NF);
         char* const wl = smem + wave * 32768 + q * 8192;
         bool done = false;
         if constexpr (EPI == EPI_F32) {
@@ -278,41 +358,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 ps.out = (float*)p.out + (size_t)split * p.split_stride;
                 if (split > 0) ps.bias = nullptr;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI_F32>(acc[i], ps, mr + i * 16 + fr, nb, fq);
+                for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI_F32, NF>(acc[i], ps, mr + i * 16 + fr, nb, fq);
                 done = true;
             }
         }
-        if constexpr (EPI == EPI_RESID) {
-            if (!p.rowmap) { gemm_epilogue_resid_tile<MI, 4, 2>(acc, p, mr + fr, nb, fq); done = true; }
+        if constexpr (EPI == EPI_RESID) {       // (row-mapped residual outputs only; the plain case returned above)
+            gemm_epilogue_resid_tile<MI, NF, 2>(acc, p, mr + fr, nb, fq);
+            done = true;
         }
-        if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
-            if ((p.N & 7) == 0 && (p.ldo & 7) == 0) { gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl); done = true; }
+        if constexpr (NF == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE)) {
+            if constexpr (PLAIN) {
+                gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mr, nb, lane, wl);
+                done = true;
+            } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
+                gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl);
+                done = true;
+            }
         }
-        if (!done) {
+        if constexpr (!PLAIN) {
+            if (!done) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI>(acc[i], p, mr + i * 16 + fr, nb, fq);
+                for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI, NF>(acc[i], p, mr + i * 16 + fr, nb, fq);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef VR_W_TIMING
+timing_tail:
     if (threadIdx.x == 0 && p.rope_table) {
         const unsigned long long tm3 = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long tm4 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* d = (unsigned long long*)p.rope_table + (size_t)blockIdx.x * 8;
+        unsigned long long* d = (unsigned long long*)p.rope_table + (size_t)blockIdx.x * 16;
         d[0] = tm0; d[1] = tm1; d[2] = tm2; d[3] = tm3; d[4] = tm4;
         d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
+        d[8] = cyc_b1w; d[9] = cyc_b1; d[10] = cyc_b2w; d[11] = cyc_b2;
         d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
-        d[7] = (unsigned long long)blockIdx.x;
+        d[7] = cy2 - cy1;                                         // shader clocks spent in the K-loop
     }
 #endif
 }
 
-template <int EPI>
-static hipError_t launch_w(GemmArgs a, hipStream_t s) {
-    const int tn = (a.N + G256_BN - 1) / G256_BN, tm = (a.M + G256_BM - 1) / G256_BM;
+template <int EPI, bool PLAIN, int NJ>
+static hipError_t launch_wp(GemmArgs a, hipStream_t s) {
+    constexpr int BN = 32 * NJ;
+    const int tn = (a.N + BN - 1) / BN, tm = (a.M + G256_BM - 1) / G256_BM;
     if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
-    auto k = gemm256w_bf16_kernel<EPI>;
+    auto k = gemm256w_bf16_kernel<EPI, PLAIN, NJ>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr = true; }
     int grid = tn * tm;
@@ -322,6 +414,14 @@ static hipError_t launch_w(GemmArgs a, hipStream_t s) {
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), G256_SMEM_BYTES, s, a);
     return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_w(const GemmArgs& a, hipStream_t s) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
+        if (!a.rowmap && !a.rowbias && (a.N & 7) == 0 && (a.ldo & 7) == 0) return launch_wp<EPI, true, 8>(a, s);
+    }
+    return launch_wp<EPI, false, 8>(a, s);
 }
 
 hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {
@@ -334,6 +434,13 @@ hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_ROPE: return launch_w<EPI_ROPE>(a, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+// 256 x 192 tile: N % 192 == 0, residual epilogue only (the SigLIP proj / fc2 GEMMs); W rows readable up to the
+// next multiple of 192 (N itself)
+hipError_t launch_gemm192w(const GemmArgs& a, int epi, hipStream_t s) {
+    if (epi != EPI_RESID || a.N % 192 || a.ksplit > 1) return hipErrorInvalidValue;
+    return launch_wp<EPI_RESID, false, 6>(a, s);
 }
 
 }  // namespace vr

@@ -10,7 +10,8 @@ enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_
 // GLDS: 128x128 4-wave tile; 256IL: 256x256 8-wave tile (needs W and A readable up to the next
 // multiple of 256 rows); 192: 256x192 tile for N % 192 == 0; AUTO picks by shape.  (The ids of the
 // retired experiment variants live on in tools/gemm_lab.)
-enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_192 = 7, GEMM_VARIANT_256IL = 9, GEMM_VARIANT_256W = 12 };
+enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_192 = 7, GEMM_VARIANT_256IL = 9, GEMM_VARIANT_256W = 12,
+                   GEMM_VARIANT_192W = 13 };
 
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M_pad][lda]
@@ -35,6 +36,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
 hipError_t launch_gemm192(const GemmArgs& a, int epilogue, hipStream_t s);
 // 256x256 tile, one wave per SIMD (gemm256w.hip): same contract as the 256-tile path of launch_gemm
 hipError_t launch_gemm256w(const GemmArgs& a, int epilogue, hipStream_t s);
+// its 256x192 form: N % 192 == 0, EPI_RESID only
+hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
 
 // ---- norms (norm.hip) --------------------------------------------------------------------
 // x f32 [rows][ldx] (dim used) -> bf16 [rows][ldo]; columns [dim, ldo) are written as zero.
