@@ -986,7 +986,7 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         if (ks > 1) {
             GemmArgs a = gemm_args(A, lda, L, T, part, E);
             a.ksplit = ks; a.split_stride = pstride;
-            HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256IL, s));
+            HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
             pend = true;
         } else {
             GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;

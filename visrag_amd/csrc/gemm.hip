@@ -165,16 +165,15 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         const double e256 = 1.45 * (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
 #ifndef VR_GEMM_AUTO_W
-#define VR_GEMM_AUTO_W 0xFE
+#define VR_GEMM_AUTO_W 0xFF
 #endif
-        // Which 256x256 kernel: the one-wave-per-SIMD kernel (gemm256w.hip) is faster and leaner everywhere in
-        // isolation (ViT qkv 230 vs 255 us, 302 vs 326 mJ), but its denser matrix-core stream pulls the
-        // shader clock down (1.9 vs 2.1 GHz sustained) and the clock recovers slowly: in the model the
-        // kernels that FOLLOW it run slower.  Measured in-model on one box (tools/ab_libs.sh, bit e of
-        // VR_GEMM_AUTO_W = epilogue e on the new kernel): fc1 (GELU) -0.75 ms/step, decoder GEMMs -0.2,
-        // ViT qkv +0.8 (attention, proj and the MLP behind it all slow down) — so plain-bf16 GEMMs with a
-        // ViT-sized M stay on the 8-wave kernel.
-        const bool w_ok = ((VR_GEMM_AUTO_W) >> epi) & 1 || (epi == EPI_BF16 && a.M < 16384);
+        // Which 256x256 kernel: the one-wave-per-SIMD kernel (gemm256w.hip) is faster and leaner in isolation
+        // everywhere (ViT qkv 230 vs 255 us, 302 vs 326 mJ), but its denser matrix-core stream pulls the shader
+        // clock down (1.9 vs 2.1 GHz sustained, well below the 1400 W cap) and the clock recovers slowly, so in
+        // the model the kernels that FOLLOW it lose part of what it gains: decide in-model, on one box
+        // (tools/ab_libs.sh; bit e of VR_GEMM_AUTO_W puts epilogue e on the new kernel).  Round 2: everything on
+        // it 48.1 ms/step, all but the ViT qkv GEMM 48.7, none (8-wave kernel, 128x128 gate/up) 50.5.
+        const bool w_ok = ((VR_GEMM_AUTO_W) >> epi) & 1;
         variant = (n_ok && e256 > e128) ? (w_ok ? GEMM_VARIANT_256W : GEMM_VARIANT_256IL) : GEMM_VARIANT_GLDS;
         if (variant == GEMM_VARIANT_256W) return launch_gemm256w(a, epi, s);
     }
