@@ -219,11 +219,11 @@ def main():
     dom = max(gemm_like, key=lambda k: gemm_like[k]["ms"])
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    kernel_names = {"vit_qkv": "vr::gemm256_bf16_kernel<0> (EPI_BF16; ViT qkv, 256x256 tile)",
+    kernel_names = {"vit_qkv": "vr::gemm256w_bf16_kernel<0, true, 8> (EPI_BF16; ViT qkv, 256x256 tile, one wave per SIMD)",
                     "vit_attn": "vr::attention_kernel<72, 2, 3> (ViT self-attention, LDS-DMA staged)",
-                    "vit_proj": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT attn proj, 256x192 tile)",
-                    "vit_fc1": "vr::gemm256_bf16_kernel<1> (EPI_GELU; ViT MLP fc1, 256x256 tile, interleaved-read main loop)",
-                    "vit_fc2": "vr::gemm192_bf16_kernel<3> (EPI_RESID; ViT MLP fc2, 256x192 tile)"}
+                    "vit_proj": "vr::gemm256w_bf16_kernel<3, false, 6> (EPI_RESID; ViT attn proj, 256x192 tile, one wave per SIMD)",
+                    "vit_fc1": "vr::gemm256w_bf16_kernel<1, true, 8> (EPI_GELU; ViT MLP fc1, 256x256 tile, one wave per SIMD)",
+                    "vit_fc2": "vr::gemm256w_bf16_kernel<3, false, 6> (EPI_RESID; ViT MLP fc2, 256x192 tile, one wave per SIMD)"}
     roofline = {"bound": "mfma", "kernel": kernel_names[dom], "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],

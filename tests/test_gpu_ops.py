@@ -24,7 +24,8 @@ def _rand(shape, seed, scale=1.0):
 
 # ------------------------------------------------------------------------------- GEMM ---
 @pytest.mark.parametrize("variant", [0, 3, 9, 12])
-@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (300, 256, 192), (1024, 512, 640), (77, 256, 2304), (700, 768, 128)])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (300, 256, 192), (1024, 512, 640), (77, 256, 2304), (700, 768, 128),
+                                   (4500, 4096, 512)])   # 288 tiles of 256 x 256: the persistent, dynamically scheduled form
 def test_gemm_bias_bf16(M, N, K, variant):
     A, W, b = _bf(_rand((M, K), 1)), _bf(_rand((N, K), 2, 0.1)), _rand((N,), 3)
     ref = A.float() @ W.float().T + b
@@ -35,7 +36,7 @@ def test_gemm_bias_bf16(M, N, K, variant):
     assert (out - ref).abs().max() < 0.05 * ref.abs().max()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 192, 64), (1000, 1152, 320), (520, 384, 4352)])
+@pytest.mark.parametrize("M,N,K", [(300, 192, 64), (1000, 1152, 320), (520, 384, 4352), (11000, 1152, 512)])
 def test_gemm_192_tile(M, N, K):
     """256x192 tile kernel (variant 7): bf16 / GELU / fp32 / residual epilogues."""
     A, W, b = _bf(_rand((M, K), 41)), _bf(_rand((N, K), 42, 0.1)), _rand((N,), 43)

@@ -63,7 +63,7 @@ def _check_no_compiler_agprs(hipcc: str, src: str, flags: List[str]) -> None:
             in_asm = True
         elif t.startswith(";;#ASMEND"):
             in_asm = False
-        elif not in_asm and (t.startswith("v_accvgpr") or "scratch_" in t and "Spill" in t):
+        elif not in_asm and t.startswith("v_accvgpr"):
             raise RuntimeError(f"{os.path.basename(src)}: hipcc generated `{t}` outside the hand-written asm — the "
                                "accumulation registers are not the compiler's to use in this file (lower the VGPR "
                                "pressure of the code around the K-loop)")

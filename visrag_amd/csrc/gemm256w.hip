@@ -27,6 +27,15 @@
 //     out of the descriptor's range (zeros written to the dead stage, no memory traffic), so every
 //     K-step runs the same code and the `vmcnt(5)` count always holds.
 //
+//   * the epilogue stages through 16 KiB of LDS above the two stages, so it does not wait for the last
+//     (out-of-range) loads to land.  A PERSISTENT form of this kernel (one workgroup per CU walking its
+//     XCD's tile range, the load pipeline running on across tile boundaries: no prologue, no workgroup
+//     launch between tiles) was built and measured in round 2 — tile period 28.7 instead of 30.1 us, but
+//     the kernel no faster: with a static split the slowest workgroup sets the end (CUs differ by 8 %,
+//     XCDs by 2.5 %), and per-XCD atomic cursors cost as much (index arithmetic and the LDS mailbox between
+//     K-steps) as they balance: ViT qkv 227 vs 221 us, proj 109 vs 102.  The hardware dispatcher already
+//     does that balancing for a one-tile-per-workgroup grid.
+//
 // NJ = 16-column fragments per wave: 8 -> 256 x 256 tile, 6 -> 256 x 192 tile (N = 1152 = 6 x 192: SigLIP proj / fc2,
 // residual epilogue only).  Slot s = strip * NJ + fragment numbers the MFMAs of a phase; the numbers in the
 // schedule above are those of NJ = 8, the NJ = 6 ones are scaled (see the constants in the kernel).
@@ -135,6 +144,9 @@ constexpr unsigned W_OOB = 0x80000000u;            // per-lane offset beyond the
 
 // PLAIN: the host has checked that the bf16-output epilogue needs no per-row lookups (no row map / row bias,
 // N and ldo multiples of 8) — the kernel then carries only the lookup-free staged epilogue.
+constexpr int W_STAGING = 4096;                            // epilogue staging per wave: one piece of 32 rows x 64 bf16
+constexpr int W_SMEM_BYTES = 2 * W_STAGE + 4 * W_STAGING;  // two stages + staging = 144 KiB
+
 template <int EPI, bool PLAIN, int NJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256w_bf16_kernel(GemmArgs p) {
     static_assert(NJ == 8 || (NJ == 6 && !PLAIN), "wave tile 128 x 128 or 128 x 96");
@@ -145,38 +157,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int SB1 = NS * 5 / 8;             // slot of the phase-1 barrier (the k-half-1 reads end at slot 2 NR - 2)
     constexpr int D1 = (NS - 1 - (SB1 + 2)) / DS + 1;   // loads issued in phase 1 (slots SB1 + 2, + DS, ...)
     constexpr int SB2 = NJ;                     // slot of the phase-2 barrier
+    constexpr int NF = NJ / 2;                  // fragments per epilogue piece: 64 or 48 columns
     static_assert(SB2 + 3 + DS * (NR - D1 - 1) < NS && SB2 + 2 + 2 * (NR - 1) < NS && 2 * NR - 2 < SB1, "schedule fits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VR_W_TIMING                   // tile anatomy (tools/w_anatomy.py, tagged builds only, one tile per workgroup)
+    const unsigned long long tm0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tm1 = 0, tm2 = 0, cy1 = 0, cy2 = 0;
+#endif
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + G256_BM - 1) / G256_BM;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    const int tt = xcd_remap(blockIdx.x, tiles_m * tiles_n * ks);
-    const int split = tt / (tiles_m * tiles_n);
-    const int t = tt - split * (tiles_m * tiles_n);
-    // grouped rasterisation, as in gemm256_bf16_kernel
-    const int GM = p.raster_gm > 0 ? p.raster_gm : 1;
-    const int gsz = GM * tiles_n;
-    const int g = t / gsz, r = t % gsz;
-    const int gm = min(GM, tiles_m - g * GM);
-    const int m0 = __builtin_amdgcn_readfirstlane((g * GM + r % gm) * G256_BM);
-    const int n0 = __builtin_amdgcn_readfirstlane((r / gm) * BN);
-
-#ifdef VR_W_TIMING                   // tile anatomy (tools/w_anatomy.py, tagged builds only): timestamps via rope_table
-    const unsigned long long tm0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long tm1 = 0, tm2 = 0;
-    unsigned cyc_b1w = 0, cyc_b1 = 0, cyc_b2w = 0, cyc_b2 = 0;     // shader clocks in the two waits / barriers of a K-step
-#endif
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int total = tiles_m * tiles_n * ks;
     const int Ks = p.K / ks;
     const int nk = Ks / GEMM_BK;
 
-    // ---- LDS-DMA addressing: wave w fills rows [64 w, 64 w + 64) of both operand tiles, 8 rows per
-    //      instruction; lane l -> row l / 8, 16-byte chunk (l % 8) ^ (row % 8) of the 128-byte k-slice
-    const char* Ab = (const char*)p.A + ((size_t)m0 * p.lda + (size_t)split * Ks) * 2;
-    const char* Wb = (const char*)p.W + ((size_t)n0 * p.ldw + (size_t)split * Ks) * 2;
-    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7FFFFFFF, 0x00020000);
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7FFFFFFF, 0x00020000);
+    const int my_first = xcd_remap(blockIdx.x, total);
+    // tile index -> (m0, n0, split); grouped rasterisation as in gemm256_bf16_kernel
+    const int GM = p.raster_gm > 0 ? p.raster_gm : 1;
+    auto coords = [&](int tt, int& m0, int& n0, int& split) {
+        split = tt / (tiles_m * tiles_n);
+        const int t = tt - split * (tiles_m * tiles_n);
+        const int gsz = GM * tiles_n;
+        const int g = t / gsz, r = t % gsz;
+        const int gm = min(GM, tiles_m - g * GM);
+        m0 = __builtin_amdgcn_readfirstlane((g * GM + r % gm) * G256_BM);
+        n0 = __builtin_amdgcn_readfirstlane((r / gm) * BN);
+        split = __builtin_amdgcn_readfirstlane(split);
+    };
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+
+    // ---- LDS-DMA addressing: wave w fills rows [64 w, 64 w + 64) of the A tile and [8 NJ w, 8 NJ (w + 1)) of
+    //      the W tile, 8 rows per instruction; lane l -> row l / 8, 16-byte chunk (l % 8) ^ (row % 8) of the
+    //      128-byte k-slice.  One descriptor per MATRIX (both below 2 GiB, checked by the launcher); a tile's
+    //      byte offset and the K offset go into the per-lane offset, the row group into the scalar offset.
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
     const unsigned lchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
     const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
     const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
@@ -184,13 +201,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned sA0 = (unsigned)wave * 8u * rgA, sW0 = (unsigned)wave * (unsigned)NJ * rgW;
     char* const dmaA = smem + wave * 8192;
     char* const dmaW = smem + G256_TILE_BYTES + wave * (NJ * 1024);
+    auto tile_off_a = [&](int m0, int split) { return ((unsigned)m0 * (unsigned)p.lda + (unsigned)split * (unsigned)Ks) * 2u; };
+    auto tile_off_w = [&](int n0, int split) { return ((unsigned)n0 * (unsigned)p.ldw + (unsigned)split * (unsigned)Ks) * 2u; };
 
-    // one of the NR loads of a K-step: d < 8 -> A row group d, else W row group d - 8 (W rows [8 NJ w, 8 NJ (w + 1)))
+    // one of the NR loads of a K-step: d < 8 -> A row group d, else W row group d - 8
     auto dma = [&](int stage, int d, unsigned vA, unsigned vW) {
         if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(dmaA + stage * W_STAGE + d * 1024), 16, vA, sA0 + d * rgA, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(dmaW + stage * W_STAGE + (d - 8) * 1024), 16, vW, sW0 + (d - 8) * rgW, 0, 0);
     };
-    auto kofs = [&](int kt) -> unsigned { return kt < nk ? (unsigned)kt * (GEMM_BK * 2) : W_OOB; };
 
     // ---- fragment addressing: row = strip * 16 + fr, chunk (kk * 4 + fq) ^ (row & 7).  One LDS pointer per
     //      (operand, stage, k-half) held in a VGPR; the strip is an immediate offset (strip * 2 KiB).
@@ -209,182 +227,186 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W_FOR_EACH_ACC(W_ZERO)
 
     bf16x8 a0[8], w0[NJ], a1[8], w1[NJ];
+    int m0, n0, split;
+    coords(my_first, m0, n0, split);
+    unsigned curA = tile_off_a(m0, split), curW = tile_off_w(n0, split);
 
-    // ---- prologue: K-steps 0 and 1 in flight, k-half-0 fragments of step 0 requested
+    // ---- prologue (first tile only): K-steps 0 and 1 in flight, k-half-0 fragments of step 0 requested
     {
-        const unsigned k0 = kofs(0), k1 = kofs(1);
+        const unsigned k1 = nk > 1 ? (unsigned)(GEMM_BK * 2) : W_OOB;
 #pragma unroll
-        for (int d = 0; d < NR; ++d) dma(0, d, lofA + k0, lofW + k0);
+        for (int d = 0; d < NR; ++d) dma(0, d, lofA + curA, lofW + curW);
 #pragma unroll
-        for (int d = 0; d < NR; ++d) dma(1, d, lofA + k1, lofW + k1);
+        for (int d = 0; d < NR; ++d) dma(1, d, lofA + curA + k1, lofW + curW + k1);
         if constexpr (NJ == 8) VR_WAIT_VM_BARRIER(16); else VR_WAIT_VM_BARRIER(14);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) w0[j] = pW[0][0][j * 128];
 #pragma unroll
         for (int i = 0; i < 8; ++i) a0[i] = pA[0][0][i * 128];
     }
-
 #ifdef VR_W_TIMING
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     tm1 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long cy1 = __builtin_amdgcn_s_memtime();
+    cy1 = __builtin_amdgcn_s_memtime();
 #endif
-    auto step = [&](auto stage_c, int kt) {
-        constexpr int S = decltype(stage_c)::value;
-        const unsigned k2 = kofs(kt + 2);
-        const unsigned vA = lofA + k2, vW = lofW + k2;
-        __builtin_amdgcn_sched_barrier(0);
-        // one auxiliary operation may follow each MFMA; sl = its slot in the phase
-        auto aux1 = [&](int sl) {
-            if (sl < 2 * NR && (sl & 1) == 0) {
-                const int q = sl >> 1;
-                if (q < NJ) w1[q] = pW[S][1][q * 128];
-                else a1[q - NJ] = pA[S][1][(q - NJ) * 128];
-            }
-            if (sl == SB1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (sl >= SB1 + 2 && (sl - (SB1 + 2)) % DS == 0) dma(S, (sl - (SB1 + 2)) / DS, vA, vW);     // loads 0 .. D1-1
+
+    {
+        // the loads of the two K-steps past the end of K go nowhere (out of the descriptors' range)
+        const unsigned nxtA = W_OOB, nxtW = W_OOB;
+
+        auto step = [&](auto stage_c, int kt) {
+            constexpr int S = decltype(stage_c)::value;
+            const int k2 = kt + 2;
+            const unsigned vA = lofA + (k2 < nk ? curA + (unsigned)k2 * (GEMM_BK * 2) : nxtA + (unsigned)(k2 - nk) * (GEMM_BK * 2));
+            const unsigned vW = lofW + (k2 < nk ? curW + (unsigned)k2 * (GEMM_BK * 2) : nxtW + (unsigned)(k2 - nk) * (GEMM_BK * 2));
             __builtin_amdgcn_sched_barrier(0);
-        };
-        auto aux2 = [&](int sl) {
-            if (sl == SB2) { if constexpr (D1 == 5) VR_WAIT_VM_BARRIER(5); else VR_WAIT_VM_BARRIER(4); }
-            if (sl >= SB2 + 3 && (sl - (SB2 + 3)) % DS == 0 && D1 + (sl - (SB2 + 3)) / DS < NR)
-                dma(S, D1 + (sl - (SB2 + 3)) / DS, vA, vW);                                              // loads D1 .. NR-1
-            if (sl >= SB2 + 2 && sl < SB2 + 2 + 2 * NR && ((sl - SB2) & 1) == 0) {
-                const int q = (sl - (SB2 + 2)) >> 1;
-                if (q < NJ) w0[q] = pW[S ^ 1][0][q * 128];
-                else a0[q - NJ] = pA[S ^ 1][0][(q - NJ) * 128];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // ---- phase 1: k-half 0, phase 2: k-half 1 (accumulator n: strip n / 8, fragment n % 8 < NJ)
+            // one auxiliary operation may follow each MFMA; sl = its slot in the phase
+            auto aux1 = [&](int sl) {
+                if (sl < 2 * NR && (sl & 1) == 0) {
+                    const int q = sl >> 1;
+                    if (q < NJ) w1[q] = pW[S][1][q * 128];
+                    else a1[q - NJ] = pA[S][1][(q - NJ) * 128];
+                }
+                if (sl == SB1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (sl >= SB1 + 2 && (sl - (SB1 + 2)) % DS == 0) dma(S, (sl - (SB1 + 2)) / DS, vA, vW);     // loads 0 .. D1-1
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto aux2 = [&](int sl) {
+                if (sl == SB2) { if constexpr (D1 == 5) VR_WAIT_VM_BARRIER(5); else VR_WAIT_VM_BARRIER(4); }
+                if (sl >= SB2 + 3 && (sl - (SB2 + 3)) % DS == 0 && D1 + (sl - (SB2 + 3)) / DS < NR)
+                    dma(S, D1 + (sl - (SB2 + 3)) / DS, vA, vW);                                              // loads D1 .. NR-1
+                if (sl >= SB2 + 2 && sl < SB2 + 2 + 2 * NR && ((sl - SB2) & 1) == 0) {
+                    const int q = (sl - (SB2 + 2)) >> 1;
+                    if (q < NJ) w0[q] = pW[S ^ 1][0][q * 128];
+                    else a0[q - NJ] = pA[S ^ 1][0][(q - NJ) * 128];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // ---- phase 1: k-half 0, phase 2: k-half 1 (accumulator n: strip n / 8, fragment n % 8 < NJ)
 #define W_P1(n, R, C0, C1, C2, C3) \
-        if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w0[(n) & 7], a0[(n) >> 3]); aux1(((n) >> 3) * NJ + ((n) & 7)); }
+            if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w0[(n) & 7], a0[(n) >> 3]); aux1(((n) >> 3) * NJ + ((n) & 7)); }
 #define W_P2(n, R, C0, C1, C2, C3) \
-        if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w1[(n) & 7], a1[(n) >> 3]); aux2(((n) >> 3) * NJ + ((n) & 7)); }
-        W_FOR_EACH_ACC(W_P1)
-        W_FOR_EACH_ACC(W_P2)
+            if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w1[(n) & 7], a1[(n) >> 3]); aux2(((n) >> 3) * NJ + ((n) & 7)); }
+            W_FOR_EACH_ACC(W_P1)
+            W_FOR_EACH_ACC(W_P2)
 #undef W_P1
 #undef W_P2
-    };
+        };
 
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(std::integral_constant<int, 0>{}, kt);
-        if (kt + 1 >= nk) break;
-        step(std::integral_constant<int, 1>{}, kt + 1);
-    }
-    VR_WAIT_VM_BARRIER(0);              // the out-of-range loads of the last two steps have written their zeros
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads (see w_mfma)
-
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(std::integral_constant<int, 0>{}, kt);
+            if (kt + 1 >= nk) break;
+            step(std::integral_constant<int, 1>{}, kt + 1);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads (see the W_MFMA note)
 #ifdef VR_W_TIMING
-    tm2 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long cy2 = __builtin_amdgcn_s_memtime();
+        tm2 = __builtin_amdgcn_s_memrealtime();
+        cy2 = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef VR_W_ABLATE_EPILOGUE          // timing experiments only (tagged builds): main loop without its epilogue
-    return;
-#endif
-    // ---- epilogue: in four pieces of 64 rows x 64 columns (64 accumulator registers read back into VGPRs at
-    //      a time; the scheduling barrier keeps hipcc from pulling the next piece's read-back up and running
-    //      out of VGPRs — it would park the overflow in accumulation registers that still hold results),
-    //      each exactly as the 128-tile kernel treats a wave tile
-    const int mrow0 = m0 + wm * 128, nb0 = n0 + wn * (16 * NJ);
-    constexpr int NF = NJ / 2;                  // fragments per piece: 64 or 48 columns
-    if constexpr (EPI == EPI_RESID) {
-        // out = resid + alpha * (acc + bias), fp32, in place: the residual of piece q + 1 is requested before piece
-        // q is combined and stored, so (one wave per SIMD, nothing else to hide it) only the first piece's load
-        // latency is exposed.  Addresses are clamped for rows >= M / columns >= N, the stores are predicated.
-        if (!p.rowmap) {
-            constexpr int MI = 2;               // pieces of 32 rows x 16 NF columns: 8 per wave
-            const float* __restrict__ resid = p.resid;
-            float* __restrict__ out = (float*)p.out;
-            f32x4 rs[2][MI][NF];
-            auto load_piece = [&](int q, f32x4 (&dst)[MI][NF]) {
-                const int h = q & 1, sg = q >> 1;
+
+        // ---- epilogue of tile (m0, n0, split).  The stages may already be receiving the next tile: staging goes
+        //      through this wave's 4 KiB above them, one piece at a time (a wave's LDS operations execute in order).
+        //      Pieces of 32 accumulator registers are read back into VGPRs one after the other; the scheduling
+        //      barriers keep hipcc from pulling later read-backs up and running out of VGPRs.
+        const int mrow0 = m0 + wm * 128, nb0 = n0 + wn * (16 * NJ);
+        char* const wl0 = smem + 2 * W_STAGE + wave * W_STAGING;
+        bool plain_resid = false;
+        if constexpr (EPI == EPI_RESID) plain_resid = !p.rowmap;
+        if constexpr (EPI == EPI_RESID) {
+            // out = resid + alpha * (acc + bias), fp32, in place: the residual of piece q + 1 is requested before
+            // piece q is combined and stored, so (one wave per SIMD, nothing else to hide it) only the first piece's
+            // load latency is exposed.  Addresses are clamped for rows >= M / columns >= N, the stores predicated.
+            if (plain_resid) {
+                constexpr int MI = 2;           // pieces of 32 rows x 16 NF columns: 8 per wave
+                const float* __restrict__ resid = p.resid;
+                float* __restrict__ out = (float*)p.out;
+                f32x4 rs[2][MI][NF];
+                auto load_piece = [&](int q, f32x4 (&dst)[MI][NF]) {
+                    const int h = q & 1, sg = q >> 1;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const size_t ro = (size_t)min(mrow0 + (sg * MI + i) * 16 + fr, p.M - 1) * p.ldo;
+                    for (int i = 0; i < MI; ++i) {
+                        const size_t ro = (size_t)min(mrow0 + (sg * MI + i) * 16 + fr, p.M - 1) * p.ldo;
 #pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        dst[i][j] = *reinterpret_cast<const f32x4*>(resid + ro + min(nb0 + (h * NF + j) * 16 + fq * 4, p.N - 4));
+                        for (int j = 0; j < NF; ++j)
+                            dst[i][j] = *reinterpret_cast<const f32x4*>(resid + ro + min(nb0 + (h * NF + j) * 16 + fq * 4, p.N - 4));
+                    }
+                };
+                load_piece(0, rs[0]);
+                f32x4 bias[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(nb0 + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int h = q & 1, sg = q >> 1;
+                    if (q < 7) load_piece(q + 1, rs[(q + 1) & 1]);
+                    f32x4 acc[MI][NF];
+#define W_RD(n, R, C0, C1, C2, C3) \
+                    if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
+                    W_FOR_EACH_ACC(W_RD)
+#undef W_RD
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int m = mrow0 + (sg * MI + i) * 16 + fr;
+#pragma unroll
+                        for (int j = 0; j < NF; ++j) {
+                            const int n = nb0 + (h * NF + j) * 16 + fq * 4;
+                            if (m < p.M && n < p.N)
+                                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q & 1][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            };
-            load_piece(0, rs[0]);
-            f32x4 bias[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(nb0 + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!plain_resid) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int h = q & 1, sg = q >> 1;
-                if (q < 7) load_piece(q + 1, rs[(q + 1) & 1]);
-                f32x4 acc[MI][NF];
+                constexpr int MI = 2;
+                const int h = q & 1, sg = q >> 1;       // column half, 32-row strip group
+                f32x4 acc[MI][NF];                      // [16-row strip][16-column fragment]
 #define W_RD(n, R, C0, C1, C2, C3) \
                 if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
                 W_FOR_EACH_ACC(W_RD)
 #undef W_RD
+                const int mr = mrow0 + sg * 32, nb = nb0 + h * (16 * NF);
+                bool done = false;
+                if constexpr (EPI == EPI_F32) {
+                    if (ks > 1) {
+                        GemmArgs ps = p;
+                        ps.out = (float*)p.out + (size_t)split * p.split_stride;
+                        if (split > 0) ps.bias = nullptr;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int m = mrow0 + (sg * MI + i) * 16 + fr;
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) {
-                        const int n = nb0 + (h * NF + j) * 16 + fq * 4;
-                        if (m < p.M && n < p.N)
-                            *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q & 1][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
+                        for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI_F32, NF>(acc[i], ps, mr + i * 16 + fr, nb, fq);
+                        done = true;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (EPI == EPI_RESID) {       // (row-mapped residual outputs)
+                    gemm_epilogue_resid_tile<MI, NF, 2>(acc, p, mr + fr, nb, fq);
+                    done = true;
+                }
+                if constexpr (NF == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE)) {
+                    if constexpr (PLAIN) {
+                        gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mr, nb, lane, wl0);
+                        done = true;
+                    } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
+                        gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl0);
+                        done = true;
+                    }
+                }
+                if constexpr (!PLAIN) {
+                    if (!done) {
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI, NF>(acc[i], p, mr + i * 16 + fr, nb, fq);
+                    }
+                }
+                // (lookup-free pieces may overlap in pairs; they share the staging buffer, whose accesses hipcc keeps
+                // in program order)
+                if (!PLAIN || (q & 1)) __builtin_amdgcn_sched_barrier(0);
             }
-#ifdef VR_W_TIMING
-            goto timing_tail;
-#else
-            return;
-#endif
         }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        constexpr int MI = 4;
-        const int h = q & 1, sg = q >> 1;       // column half, 64-row strip group
-        f32x4 acc[MI][NF];                      // [16-row strip][16-column fragment]
-#define W_RD(n, R, C0, C1, C2, C3) \
-        if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 5) == sg) W_READ(acc[((n) >> 3) & 3][((n) & 7) % NF], C0, C1, C2, C3);
-        W_FOR_EACH_ACC(W_RD)
-#undef W_RD
-        const int mr = mrow0 + sg * 64, nb = nb0 + h * (16 * NF);
-        char* const wl = smem + wave * 32768 + q * 8192;
-        bool done = false;
-        if constexpr (EPI == EPI_F32) {
-            if (ks > 1) {
-                GemmArgs ps = p;
-                ps.out = (float*)p.out + (size_t)split * p.split_stride;
-                if (split > 0) ps.bias = nullptr;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI_F32, NF>(acc[i], ps, mr + i * 16 + fr, nb, fq);
-                done = true;
-            }
-        }
-        if constexpr (EPI == EPI_RESID) {       // (row-mapped residual outputs only; the plain case returned above)
-            gemm_epilogue_resid_tile<MI, NF, 2>(acc, p, mr + fr, nb, fq);
-            done = true;
-        }
-        if constexpr (NF == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE)) {
-            if constexpr (PLAIN) {
-                gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mr, nb, lane, wl);
-                done = true;
-            } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
-                gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl);
-                done = true;
-            }
-        }
-        if constexpr (!PLAIN) {
-            if (!done) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI, NF>(acc[i], p, mr + i * 16 + fr, nb, fq);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
 #ifdef VR_W_TIMING
-timing_tail:
     if (threadIdx.x == 0 && p.rope_table) {
         const unsigned long long tm3 = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -392,7 +414,6 @@ timing_tail:
         unsigned long long* d = (unsigned long long*)p.rope_table + (size_t)blockIdx.x * 16;
         d[0] = tm0; d[1] = tm1; d[2] = tm2; d[3] = tm3; d[4] = tm4;
         d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
-        d[8] = cyc_b1w; d[9] = cyc_b1; d[10] = cyc_b2w; d[11] = cyc_b2;
         d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
         d[7] = cy2 - cy1;                                         // shader clocks spent in the K-loop
     }
@@ -404,15 +425,17 @@ static hipError_t launch_wp(GemmArgs a, hipStream_t s) {
     constexpr int BN = 32 * NJ;
     const int tn = (a.N + BN - 1) / BN, tm = (a.M + G256_BM - 1) / G256_BM;
     if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
-    auto k = gemm256w_bf16_kernel<EPI, PLAIN, NJ>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr = true; }
-    int grid = tn * tm;
+    // (the LDS-DMA addresses whole matrices through 32-bit offsets)
+    if ((size_t)tm * G256_BM * a.lda * 2 >= (1ull << 31) || (size_t)tn * BN * a.ldw * 2 >= (1ull << 31)) return hipErrorInvalidValue;
+    int total = tn * tm;
     if (a.ksplit > 1) {
         if (EPI != EPI_F32 || a.K % (a.ksplit * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
-        grid *= a.ksplit;
+        total *= a.ksplit;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), G256_SMEM_BYTES, s, a);
+    auto k = gemm256w_bf16_kernel<EPI, PLAIN, NJ>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM_BYTES); attr = true; }
+    hipLaunchKernelGGL(k, dim3(total), dim3(256), W_SMEM_BYTES, s, a);
     return hipGetLastError();
 }
 
