@@ -41,6 +41,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Kernels with more than 64 KiB of dynamic LDS: raise the function's limit once per DEVICE (the attribute lives in
+// the device's copy of the module; one process may drive several devices).  `done` is the call site's static mask.
+inline void set_max_dynamic_lds(const void* fn, int bytes, unsigned long long& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (!((done >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done |= 1ull << dev;
+    }
+}
 // counted wait + raw barrier: lets LDS-DMA loads younger than the N-th stay in flight across the
 // barrier (__syncthreads() would drain the whole queue)
 #define VR_WAIT_VM_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")

@@ -115,8 +115,8 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
         const int tn = (a.N + G256_BN - 1) / G256_BN, tm = (a.M + G256_BM - 1) / G256_BM;
         if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;   // 4 is within noise of the best for big M; few m-tiles -> n-major
         auto k = gemm256_bf16_kernel<EPI>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_SMEM_BYTES); attr = true; }
+        static unsigned long long attr = 0;     // bit d: set on device d
+        set_max_dynamic_lds((const void*)k, G256_SMEM_BYTES, attr);
         int grid = tn * tm;
         if (a.ksplit > 1) {
             if (EPI != EPI_F32 || a.K % (a.ksplit * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
@@ -133,8 +133,8 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
         a.raster_gm = tm <= 32 ? tm : 4;
     }
     auto k = gemm_bf16_kernel<EPI>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)k, GEMM_SMEM_BYTES, attr);
     hipLaunchKernelGGL(k, dim3(tiles), dim3(256), GEMM_SMEM_BYTES, s, a);
     return hipGetLastError();
 }

@@ -111,8 +111,8 @@ static hipError_t launch192_t(GemmArgs a, hipStream_t s) {
     if (a.raster_gm <= 0) a.raster_gm = 4;
     const int tiles = (a.N / G192_BN) * ((a.M + G192_BM - 1) / G192_BM);
     auto k = gemm192_bf16_kernel<EPI>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G192_SMEM); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)k, G192_SMEM, attr);
     hipLaunchKernelGGL(k, dim3(tiles), dim3(512), G192_SMEM, s, a);
     return hipGetLastError();
 }

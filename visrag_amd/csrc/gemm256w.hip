@@ -433,8 +433,8 @@ static hipError_t launch_wp(GemmArgs a, hipStream_t s) {
         total *= a.ksplit;
     }
     auto k = gemm256w_bf16_kernel<EPI, PLAIN, NJ>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM_BYTES); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)k, W_SMEM_BYTES, attr);
     hipLaunchKernelGGL(k, dim3(total), dim3(256), W_SMEM_BYTES, s, a);
     return hipGetLastError();
 }

@@ -106,8 +106,8 @@ hipError_t launch_patch_embed(const uint8_t* const* imgs, int n_imgs, int H, int
     PatchArgs a{};
     a.imgs = imgs; a.H = H; a.W = W; a.P = P; a.gw = W / P; a.N = (H / P) * (W / P); a.g = g; a.Kreal = Kreal;
     const int tiles = (g.N / GEMM_BN) * ((g.M + GEMM_BM - 1) / GEMM_BM);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)patch_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)patch_embed_kernel, GEMM_SMEM_BYTES, attr);
     hipLaunchKernelGGL(patch_embed_kernel, dim3(tiles), dim3(256), GEMM_SMEM_BYTES, s, a);
     return hipGetLastError();
 }

@@ -391,8 +391,8 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     const int q_tiles = (a.nq + 127) / 128;
     const int n_tiles = (int)((a.n_docs + 127) / 128);
     auto k = search_sweep_kernel<KP>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEP_SMEM); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)k, SWEEP_SMEM, attr);
     hipError_t e;
     const float* thr = nullptr;
     // (a handful of queries: the chunks warm their thresholds up themselves — cheaper than two more launches)

@@ -362,8 +362,8 @@ static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s)
     const int n_tiles = (int)((a.n_docs + 255) / 256);
     const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
     auto k = search_sweep256_kernel<KP>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SWEEP256_SMEM); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)k, SWEEP256_SMEM, attr);
     hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

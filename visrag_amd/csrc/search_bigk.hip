@@ -205,8 +205,8 @@ hipError_t launch_topk_merge_big(const float* scores, const int64_t* ids, int n_
     if (k <= 0 || total > MERGE_BIG_MAX) return hipErrorInvalidValue;
     int n2 = 64;
     while (n2 < total) n2 <<= 1;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)topk_merge_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_BIG_MAX * 8); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)topk_merge_big_kernel, MERGE_BIG_MAX * 8, attr);
     hipLaunchKernelGGL(topk_merge_big_kernel, dim3(nq), dim3(256), (size_t)n2 * 8, s, scores, ids, n_parts, nq, k, n2,
                        out_scores, out_ids);
     return hipGetLastError();

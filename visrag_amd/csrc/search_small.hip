@@ -151,8 +151,8 @@ template <int KP>
 static hipError_t launch_t(const SearchArgs& a, hipStream_t s) {
     const int lds = a.dim * 32 + (int)sizeof(StreamLds);
     auto k = search_stream_kernel<KP>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2560 * 32 + (int)sizeof(StreamLds)); attr = true; }
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)k, 2560 * 32 + (int)sizeof(StreamLds), attr);
     int rows = (int)((a.n_docs + SS_WG - 1) / SS_WG);
     rows = (rows + 15) / 16 * 16;
     hipLaunchKernelGGL(k, dim3(SS_WG), dim3(512), lds, s, a, rows);
