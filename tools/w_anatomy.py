@@ -19,11 +19,12 @@ for (M, N, K, epi) in shapes:
     A = torch.randn((M, K), device="cuda").to(torch.bfloat16)
     W = (torch.randn((Np, K), device="cuda") * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda")
-    out = torch.zeros((M, N), device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros((M, N), device="cuda", dtype=torch.float32 if epi in (2, 3) else torch.bfloat16)
+    resid = out if epi == 3 else None
     tiles = (M // 256) * (Np // 256)
     dbg = torch.zeros((tiles, 16), dtype=torch.int64, device="cuda")
     for it in range(3):
-        _lib.check(lib.vr_op_gemm(0, P(A), K, P(W), K, M, N, K, epi, P(bias), None, 1.0, P(out), N, None, P(dbg), 0, 12, s))
+        _lib.check(lib.vr_op_gemm(0, P(A), K, P(W), K, M, N, K, epi, P(bias), P(resid), 0.0 if epi == 3 else 1.0, P(out), N, None, P(dbg), 0, 12, s))
     torch.cuda.synchronize()
     d = dbg.cpu().numpy()
     t = d[:, :5].astype(np.float64) * 0.01          # us

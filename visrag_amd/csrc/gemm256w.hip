@@ -372,7 +372,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int mr = mrow0 + sg * 32, nb = nb0 + h * (16 * NF);
                 bool done = false;
                 if constexpr (EPI == EPI_F32) {
-                    if (ks > 1) {
+                    // fp32 outputs without per-row lookups (incl. the split-K partial products: split s writes to its
+                    // own plane, the bias goes with split 0): bias requested once per piece, predicated vector stores.
+                    // The shared per-row epilogue (a branch nest and a dependent bias load per fragment) took 16.9 us
+                    // of a 34 us launch on the decoder's o-projection shape.
+                    if (!p.rowmap && !p.rowbias) {
+                        float* __restrict__ out = (float*)p.out + (size_t)split * p.split_stride;
+                        const float* bp = split == 0 ? p.bias : nullptr;
+                        f32x4 bias[NF];
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            bias[j] = bp ? *reinterpret_cast<const f32x4*>(bp + min(nb + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            const int m = mr + i * 16 + fr;
+#pragma unroll
+                            for (int j = 0; j < NF; ++j) {
+                                const int n = nb + j * 16 + fq * 4;
+                                if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = acc[i][j] + bias[j];
+                            }
+                        }
+                        done = true;
+                    } else if (ks > 1) {
                         GemmArgs ps = p;
                         ps.out = (float*)p.out + (size_t)split * p.split_stride;
                         if (split > 0) ps.bias = nullptr;
