@@ -17,7 +17,7 @@ from typing import Iterable, List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "norm.hip", "attention.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip",
+SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "norm.hip", "attention.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip", "search256w.hip",
            "search_small.hip", "search_bigk.hip", "resize.hip", "pack.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: relaxed NaN handling only (infinities are honoured: masked scores are -inf).  Without it
@@ -28,7 +28,7 @@ FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nan
 # gemm256w.hip hand-allocates the accumulation registers inside asm statements; hipcc only sees them as clobbers,
 # so if it ever runs out of VGPRs there it parks the overflow in registers that hold results.  The build checks
 # the generated code: outside the kernel's own asm there must be no accumulation-register traffic at all.
-AGPR_CHECKED = {"gemm256w.hip"}
+AGPR_CHECKED = {"gemm256w.hip", "search256w.hip"}
 
 
 def lib_path(tag: str = "") -> str:

@@ -115,6 +115,9 @@ int search_stream_chunks();
 hipError_t launch_search_stream(const SearchArgs& a, int kp, hipStream_t s);   // sweep only; merge: search_merge_wg_kernel
 bool search_uses_256(int nq);         // more than 128 queries: main sweep on the 256^2 tile (search256.hip)
 hipError_t launch_sweep256(const SearchArgs& a, int kp, const float* thr, hipStream_t s);
+// the same sweep on the one-wave-per-SIMD tile (search256w.hip; dim % 128 == 0): sweep only, launch_sweep256 merges
+bool sweep256w_ok(const SearchArgs& a);
+hipError_t launch_sweep256w(const SearchArgs& a, int kp, const float* thr, hipStream_t s);
 // k > 26 (search_bigk.hip): radix select over the block's score rows S + exact re-score; k <= search_bigk_max()
 int search_bigk_max();
 hipError_t launch_search_bigk(const SearchArgs& a, const float* S, size_t ldS, int q0, int nq_block, hipStream_t s);

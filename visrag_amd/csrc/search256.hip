@@ -361,11 +361,19 @@ static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s)
     const int q_tiles = (a.nq + 255) / 256;
     const int n_tiles = (int)((a.n_docs + 255) / 256);
     const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
-    auto k = search_sweep256_kernel<KP>;
-    static unsigned long long attr = 0;     // bit d: set on device d
-    set_max_dynamic_lds((const void*)k, SWEEP256_SMEM, attr);
-    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr, 0);
-    hipError_t e = hipGetLastError();
+#ifndef VR_SWEEP_W
+#define VR_SWEEP_W 1
+#endif
+    hipError_t e;
+    if (VR_SWEEP_W && sweep256w_ok(a)) {     // the one-wave-per-SIMD form of the sweep (search256w.hip)
+        e = launch_sweep256w(a, KP, thr, s);
+    } else {
+        auto k = search_sweep256_kernel<KP>;
+        static unsigned long long attr = 0;     // bit d: set on device d
+        set_max_dynamic_lds((const void*)k, SWEEP256_SMEM, attr);
+        hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(512), SWEEP256_SMEM, s, a, q_tiles, tpc, thr, 0);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(search_merge256_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, a);   // one workgroup per query
     return hipGetLastError();
