@@ -973,10 +973,23 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
     // summed, in a fixed order, by the RMSNorm that follows anyway (launch_rmsnorm_accum), which also
     // applies the scaled residual update — no reduction pass, no atomics, deterministic.
     int ks = 1;
+    int proj_variant = GEMM_VARIANT_256W;
     {
-        const long tiles = (long)((T + 255) / 256) * ((E + 255) / 256);
-        for (int cand = DEC_KSPLIT_MAX; cand > 1; --cand)
-            if (tiles * cand <= 256 && E % (cand * 64) == 0 && m->Ip % (cand * 64) == 0) { ks = cand; break; }
+#ifndef VR_DEC_PROJ_192
+#define VR_DEC_PROJ_192 1
+#endif
+        // 256 x 192 tiles when E allows (2304 = 12 x 192): 108 tiles x 2 splits = 216 workgroups write TWO partial
+        // planes instead of 81 x 3 = 243 writing three — the fp32 partials (and their re-read by the RMSNorm that
+        // sums them) are what these launches spend their epilogue on, at the HBM's pace
+        const long t192 = (long)((T + 255) / 256) * (E / 192);
+        if (VR_DEC_PROJ_192 && E % 192 == 0 && t192 * 2 <= 256 && t192 * 2 > 160 && E % 128 == 0 && m->Ip % 128 == 0) {
+            ks = 2;
+            proj_variant = GEMM_VARIANT_192W;
+        } else {
+            const long tiles = (long)((T + 255) / 256) * ((E + 255) / 256);
+            for (int cand = DEC_KSPLIT_MAX; cand > 1; --cand)
+                if (tiles * cand <= 256 && E % (cand * 64) == 0 && m->Ip % (cand * 64) == 0) { ks = cand; break; }
+        }
         if (m->taps_on) ks = 1;          // (taps read h between the projection and the next norm)
     }
     const size_t pstride = (size_t)T * E;
@@ -986,7 +999,7 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         if (ks > 1) {
             GemmArgs a = gemm_args(A, lda, L, T, part, E);
             a.ksplit = ks; a.split_stride = pstride;
-            HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
+            HIPCHK(launch_gemm(a, EPI_F32, proj_variant, s));
             pend = true;
         } else {
             GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;

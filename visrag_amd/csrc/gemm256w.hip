@@ -396,11 +396,13 @@ hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {
     }
 }
 
-// 256 x 192 tile: N % 192 == 0, residual epilogue only (the SigLIP proj / fc2 GEMMs); W rows readable up to the
-// next multiple of 192 (N itself)
+// 256 x 192 tile: N % 192 == 0, residual (the SigLIP proj / fc2 GEMMs) and fp32 (split-K partial products of the
+// decoder's o / down projections) epilogues; W rows readable up to the next multiple of 192 (N itself)
 hipError_t launch_gemm192w(const GemmArgs& a, int epi, hipStream_t s) {
-    if (epi != EPI_RESID || a.N % 192 || a.ksplit > 1) return hipErrorInvalidValue;
-    return launch_wp<EPI_RESID, false, 6>(a, s);
+    if (a.N % 192) return hipErrorInvalidValue;
+    if (epi == EPI_RESID && a.ksplit <= 1) return launch_wp<EPI_RESID, false, 6>(a, s);
+    if (epi == EPI_F32) return launch_wp<EPI_F32, false, 6>(a, s);          // incl. split-K partial products
+    return hipErrorInvalidValue;
 }
 
 }  // namespace vr
