@@ -176,7 +176,9 @@ int vr_resize_bicubic(int device_id, const uint8_t* src, int32_t src_on_device, 
  *   1 bf16 out = gelu_erf(acc + bias)  4 bf16 out[N/2] = silu(gate)*up (16-row interleaved W)
  *   2 f32  out = acc + bias            5 bf16 out = rope(acc) for col < rope_cols (head 64)
  * bias (f32[N]) and resid (f32[M][ldo]) may be NULL.  variant: 3 = the engine's own choice,
- * 0 = 128x128 tile, 7 = 256x192 tile (N % 192 == 0), 9 = 256x256 tile. */
+ * 0 = 128x128 tile, 7 = 256x192 tile (N % 192 == 0), 9 = 256x256 tile (8 waves), 12 = 256x256 tile with one
+ * wave per SIMD (what the engine uses for its big GEMMs), 13 = its 256x192 form (N % 192 == 0; epilogues 2, 3).
+ * Buffers padded to a multiple of 256 rows for the 256-row tiles. */
 int vr_op_gemm(int device_id, const void* A, int32_t lda, const void* W, int32_t ldw,
                int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* bias,
                const float* resid, float alpha, void* out, int32_t ldo,
