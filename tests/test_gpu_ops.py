@@ -46,9 +46,11 @@ def test_gemm_192_tile(M, N, K):
     np.testing.assert_allclose(op_gemm(Ad, Wd, 1, bias=bd, variant=7).float().cpu().numpy(),
                                torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=2e-2)
     r = _rand((M, N), 44)
-    for variant in (7, 13):             # 13: the one-wave-per-SIMD form of the tile (residual epilogue only)
+    for variant in (7, 13):             # 13: the one-wave-per-SIMD form of the tile (residual and fp32 epilogues)
         out = op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.5, out_dtype=torch.float32, variant=variant).cpu()
         np.testing.assert_allclose(out.numpy(), (r + 0.5 * acc).numpy(), rtol=1e-5, atol=1e-4)
+        out = op_gemm(Ad, Wd, 2, bias=bd, out_dtype=torch.float32, variant=variant).cpu()
+        np.testing.assert_allclose(out.numpy(), acc.numpy(), rtol=1e-5, atol=1e-4)
 
 
 def test_gemm_identity_asymmetric():

@@ -999,7 +999,7 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         if (ks > 1) {
             GemmArgs a = gemm_args(A, lda, L, T, part, E);
             a.ksplit = ks; a.split_stride = pstride;
-            HIPCHK(launch_gemm(a, EPI_F32, proj_variant, s));
+            HIPCHK(launch_gemm(a, EPI_F32, gemm256w_fits(a, proj_variant == GEMM_VARIANT_192W ? 192 : 256) ? proj_variant : GEMM_VARIANT_256IL, s));
             pend = true;
         } else {
             GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;

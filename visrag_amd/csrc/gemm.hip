@@ -150,7 +150,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
 #define VR_GEMM_AUTO_192W 1
 #endif
         if (a.N % 192 == 0 && a.N % 256 != 0 && a.N <= 1536 && a.M >= 4096 && epi <= EPI_RESID) {
-            if (VR_GEMM_AUTO_192W && epi == EPI_RESID && !a.rowmap) return launch_gemm192w(a, epi, s);
+            if (VR_GEMM_AUTO_192W && epi == EPI_RESID && !a.rowmap && gemm256w_fits(a, 192)) return launch_gemm192w(a, epi, s);
             return launch_gemm192(a, epi, s);
         }
         // 256x256 tiles when N is a multiple of 256 or wide enough that one partial tile column costs
@@ -173,7 +173,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
         // the model the kernels that FOLLOW it lose part of what it gains: decide in-model, on one box
         // (tools/ab_libs.sh; bit e of VR_GEMM_AUTO_W puts epilogue e on the new kernel).  Round 2: everything on
         // it 48.1 ms/step, all but the ViT qkv GEMM 48.7, none (8-wave kernel, 128x128 gate/up) 50.5.
-        const bool w_ok = ((VR_GEMM_AUTO_W) >> epi) & 1;
+        const bool w_ok = (((VR_GEMM_AUTO_W) >> epi) & 1) && gemm256w_fits(a, 256);     // (else: the 8-wave kernel, 64-bit addresses)
         variant = (n_ok && e256 > e128) ? (w_ok ? GEMM_VARIANT_256W : GEMM_VARIANT_256IL) : GEMM_VARIANT_GLDS;
         if (variant == GEMM_VARIANT_256W) return launch_gemm256w(a, epi, s);
     }

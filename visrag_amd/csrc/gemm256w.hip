@@ -51,6 +51,8 @@
 
 namespace vr {
 
+bool gemm256w_fits(const GemmArgs& a, int bn);
+
 namespace {
 
 constexpr int W_STAGE = 2 * G256_TILE_BYTES;       // A tile + W tile = 64 KiB
@@ -362,8 +364,7 @@ static hipError_t launch_wp(GemmArgs a, hipStream_t s) {
     constexpr int BN = 32 * NJ;
     const int tn = (a.N + BN - 1) / BN, tm = (a.M + G256_BM - 1) / G256_BM;
     if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
-    // (the LDS-DMA addresses whole matrices through 32-bit offsets)
-    if ((size_t)tm * G256_BM * a.lda * 2 >= (1ull << 31) || (size_t)tn * BN * a.ldw * 2 >= (1ull << 31)) return hipErrorInvalidValue;
+    if (!gemm256w_fits(a, BN)) return hipErrorInvalidValue;
     int total = tn * tm;
     if (a.ksplit > 1) {
         if (EPI != EPI_F32 || a.K % (a.ksplit * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
@@ -382,6 +383,12 @@ static hipError_t launch_w(const GemmArgs& a, hipStream_t s) {
         if (!a.rowmap && !a.rowbias && (a.N & 7) == 0 && (a.ldo & 7) == 0) return launch_wp<EPI, true, 8>(a, s);
     }
     return launch_wp<EPI, false, 8>(a, s);
+}
+
+// the LDS-DMA addresses whole matrices through 32-bit offsets: both operands (rows padded to the tile) below 2 GiB
+bool gemm256w_fits(const GemmArgs& a, int bn) {
+    const size_t tm = (a.M + G256_BM - 1) / G256_BM, tn = (a.N + bn - 1) / bn;
+    return tm * G256_BM * (size_t)a.lda * 2 < (1ull << 31) && tn * bn * (size_t)a.ldw * 2 < (1ull << 31);
 }
 
 hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {

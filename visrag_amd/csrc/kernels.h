@@ -36,6 +36,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
 hipError_t launch_gemm192(const GemmArgs& a, int epilogue, hipStream_t s);
 // 256x256 tile, one wave per SIMD (gemm256w.hip): same contract as the 256-tile path of launch_gemm
 hipError_t launch_gemm256w(const GemmArgs& a, int epilogue, hipStream_t s);
+bool gemm256w_fits(const GemmArgs& a, int tile_cols);   // its 32-bit LDS-DMA offsets cover both operands
 // its 256x192 form: N % 192 == 0, EPI_RESID and EPI_F32 (incl. ksplit)
 hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
 
