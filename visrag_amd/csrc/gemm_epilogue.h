@@ -344,9 +344,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4]
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[i][j] + bias[j];
                 if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                const bf16x4 o = __builtin_convertvector(v, bf16x4);       // two v_cvt_pk_bf16_f32
                 const int c = j * 2 + (fq >> 1);
                 *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
             }
@@ -355,20 +353,31 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4]
     // row-wise read-back (same wave: its LDS operations execute in order), full-line stores, no lookups
     bf16_t* out = (bf16_t*)p.out;
     if constexpr (EPI == EPI_SWIGLU) {
+        u32x4 d[MI];
 #pragma unroll
         for (int it = 0; it < MI; ++it) {
             const int row = it * 16 + (lane >> 2), c = lane & 3;
-            const u32x4 d = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4));
+            d[it] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < MI; ++it) {
+            const int row = it * 16 + (lane >> 2), c = lane & 3;
             const int m = mrow0 + row, n = nb / 2 + c * 8;
-            if (m < p.M && 2 * n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n) = d;
+            if (m < p.M && 2 * n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n) = d[it];
         }
     } else {
+        // (all read-backs first: behind the predicated stores hipcc issues them one at a time, an LDS round trip each)
+        u32x4 d[MI * 2];
 #pragma unroll
         for (int it = 0; it < MI * 2; ++it) {
             const int row = it * 8 + (lane >> 3), c = lane & 7;
-            const u32x4 d = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4));
+            d[it] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < MI * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), c = lane & 7;
             const int m = mrow0 + row, n = nb + c * 8;
-            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n) = d;
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n) = d[it];
         }
     }
 }
