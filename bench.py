@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--search-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
-                    help="also measure encode with two batches in flight (vr_model_clone + two HIP streams); "
+                    help="measure encode with two batches in flight (vr_model_clone + two HIP streams) even with --no-extras; "
                          "reported under \"pipelined\", never as `value`")
     ap.add_argument("--cpu-pages", type=int, default=16,
                     help="pages of the CPU baseline sample (one reference-sized batch of 16 by default; 64 = all of "
@@ -137,7 +137,7 @@ def main():
 
     # ---- optional: two batches in flight (own workspace + stream each, shared weights); outside `value`
     pipelined = None
-    if args.pipelined:
+    if args.pipelined or not args.no_extras:
         enc2 = enc.clone()
         slots = [(enc, torch.cuda.Stream(device=dev), out), (enc2, torch.cuda.Stream(device=dev), torch.empty_like(out))]
 

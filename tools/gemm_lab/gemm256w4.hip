@@ -1,4 +1,6 @@
-// 256 x 256 x 64 GEMM with FOUR waves, 128 x 128 per wave (variant 12).
+// 256 x 256 x 64 GEMM with FOUR waves, 128 x 128 per wave (lab variant 14) — the round-1 attempt at what
+// visrag_amd/csrc/gemm256w.hip became in round 2 (there: accumulators hand-allocated, loads two steps ahead and
+// spread over the K-step; here: one barrier per K-step, loads in a burst, compiler-allocated accumulators: -8 %).
 //
 // The 8-wave kernel's main loop is LDS-bandwidth bound: per K-step its waves read 8 x 24 KiB of
 // fragments (12 reads feed 32 MFMAs) and the LDS-DMA writes 64 KiB — 256 KiB through a 128 B/clk

@@ -4,9 +4,9 @@
 #include "kernels.h"
 
 namespace vr {
-// variant ids of the round-1 experiments (0 / 3 / 7 / 9 are the product's, see kernels.h)
+// variant ids of the round-1 experiments (0 / 3 / 7 / 9 / 12 / 13 are the product's, see kernels.h)
 enum LabVariant { LAB_REG = 1, LAB_256 = 2, LAB_256P4 = 4, LAB_256MID = 5, LAB_256STAG = 6, LAB_32 = 8, LAB_256P = 10,
-                  LAB_256T = 11, LAB_256W4 = 12 };
+                  LAB_256T = 11, LAB_256W4 = 14 };    // (12 / 13 are the product's one-wave-per-SIMD kernels since round 2)
 hipError_t launch_gemm_lab(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 hipError_t launch_gemm32(const GemmArgs& a, int epilogue, hipStream_t s);      // 256^2 on v_mfma_f32_32x32x16_bf16
 hipError_t launch_gemm256p(const GemmArgs& a, int epilogue, hipStream_t s);    // persistent, one workgroup per CU

@@ -45,5 +45,4 @@ for (M, N, K, epi) in shapes:
                       "store_ack_us": [round(float(np.median(epi_w)), 2), round(float(epi_w.max()), 2)],
                       "gap_between_wgs_on_a_cu_us": [round(float(np.median(gaps)), 2), round(float(gaps.max()), 2)],
                       "kloop_mhz": round(float(np.median(d[:, 7] / np.maximum(loop, 1e-3))), 0), "kstep_clocks": round(float(np.median(d[:, 7])) / (K // 64), 0),
-                      "per_kstep_clocks_wait_reads/barrier1/wait_dma/barrier2": [round(float(np.median(d[:, 8 + i])) / (K // 64), 0) for i in range(4)],
                       "first_start_spread_us": round(float(np.sort(t[:, 0])[min(255, tiles - 1)] - t0), 2)}))
