@@ -211,3 +211,21 @@ def test_device_resolution(monkeypatch):
     assert _device_index("cuda:2") == 2 and _device_index(5) == 5 and _device_index(torch.float16) is None
     with pytest.raises(RuntimeError):
         _device_index("cpu")
+
+
+def test_build_flags_compiler_use_of_accumulation_registers():
+    """build.py disassembles the one-wave-per-SIMD kernels (their accumulators are hand-allocated in asm text, the
+    compiler only sees clobbers): any accumulation-register instruction outside the asm blocks must fail the build."""
+    from visrag_amd.build import AGPR_CHECKED, SOURCES, agpr_violations
+    ok = """
+        v_add_f32 v1, v2, v3
+        ;;#ASMSTART
+        v_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]
+        v_accvgpr_read_b32 v9, a3
+        ;;#ASMEND
+        s_endpgm
+    """
+    assert agpr_violations(ok) == []
+    spill = ok + "\n\tv_accvgpr_write_b32 a17, v1 ; the compiler parking a VGPR\n"
+    assert agpr_violations(spill) == ["v_accvgpr_write_b32 a17, v1 ; the compiler parking a VGPR"]
+    assert AGPR_CHECKED <= set(SOURCES) and {"gemm256w.hip", "search256w.hip"} <= AGPR_CHECKED

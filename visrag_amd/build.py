@@ -51,22 +51,30 @@ def _newest_header() -> float:
     return t
 
 
-def _check_no_compiler_agprs(hipcc: str, src: str, flags: List[str]) -> None:
-    r = subprocess.run([hipcc, *[f for f in flags if f != "-fPIC"], "--cuda-device-only", "-S", src, "-o", "-"],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr[-2000:]}")
-    in_asm = False
-    for ln in r.stdout.splitlines():
+def agpr_violations(asm_text: str) -> List[str]:
+    """Instructions of a `hipcc -S` listing that touch accumulation registers outside `;;#ASMSTART ... ;;#ASMEND`."""
+    bad, in_asm = [], False
+    for ln in asm_text.splitlines():
         t = ln.strip()
         if t.startswith(";;#ASMSTART"):
             in_asm = True
         elif t.startswith(";;#ASMEND"):
             in_asm = False
         elif not in_asm and t.startswith("v_accvgpr"):
-            raise RuntimeError(f"{os.path.basename(src)}: hipcc generated `{t}` outside the hand-written asm — the "
-                               "accumulation registers are not the compiler's to use in this file (lower the VGPR "
-                               "pressure of the code around the K-loop)")
+            bad.append(t)
+    return bad
+
+
+def _check_no_compiler_agprs(hipcc: str, src: str, flags: List[str]) -> None:
+    r = subprocess.run([hipcc, *[f for f in flags if f != "-fPIC"], "--cuda-device-only", "-S", src, "-o", "-"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr[-2000:]}")
+    bad = agpr_violations(r.stdout)
+    if bad:
+        raise RuntimeError(f"{os.path.basename(src)}: hipcc generated `{bad[0]}` (+{len(bad) - 1} more) outside the hand-written "
+                           "asm — the accumulation registers are not the compiler's to use in this file (lower the VGPR "
+                           "pressure of the code around the K-loop)")
 
 
 def build(force: bool = False, verbose: bool = True, tag: str = "", defines: Optional[Iterable[str]] = None) -> str:
