@@ -2,7 +2,7 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visrag_amd.engine import HipIndex
-nd, dim = 100_000, 2304
+nd, dim = int(os.environ.get("ND", "100000")), 2304      # ND=12500: one shard of the 8-GPU run
 g = torch.Generator(device="cuda").manual_seed(0)
 C = torch.randn((nd, dim), generator=g, device="cuda"); C = C / C.norm(dim=1, keepdim=True)
 ix = HipIndex(dim, nd); ix.add(C)

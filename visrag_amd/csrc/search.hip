@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_t
 // still fit one round of workgroups (256 for 1000 queries), so the wider sample costs no time, and
 // the sweep's filter lets ~450 instead of ~1900 candidates per query through (1k x 100k: 0.567 ->
 // 0.536 ms with 8 -> 32 tiles, 0.547 with 64).
-constexpr int PRE_CHUNKS = 32;     // sampled 128-row tiles = 4096 rows
+constexpr int PRE_CHUNKS = 32;     // sampled 128-row tiles = 4096 rows at most (8 or 16 for small shards: one tile in eight)
 constexpr int PRE_GROUPS = 32;     // group maxima per (query, tile)
 
-__global__ __launch_bounds__(256) void search_prepass_kernel(SearchArgs p, int q_tiles, int tile_step,
+__global__ __launch_bounds__(256) void search_prepass_kernel(SearchArgs p, int q_tiles, int tile_step, int pre_chunks,
                                                              float* __restrict__ gmax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,21 +163,21 @@ __global__ __launch_bounds__(256) void search_prepass_kernel(SearchArgs p, int q
             for (int i = 0; i < 4; ++i)
                 if (doc0 + wm * 64 + i * 16 + fr < p.n_docs) m = fmaxf(m, acc[i][j][r]);
             const int qn = q0 + wn * 64 + j * 16 + fq * 4 + r;
-            gmax[((size_t)qn * PRE_CHUNKS + chunk) * PRE_GROUPS + wm * 16 + fr] = m;
+            gmax[((size_t)qn * pre_chunks + chunk) * PRE_GROUPS + wm * 16 + fr] = m;
         }
     }
 }
 
 template <int KP>
-__global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict__ gmax, int nq_pad,
+__global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict__ gmax, int nq_pad, int pre_chunks,
                                                          float* __restrict__ thr) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq_pad) return;
-    const float* g = gmax + (size_t)q * PRE_CHUNKS * PRE_GROUPS;
+    const float* g = gmax + (size_t)q * pre_chunks * PRE_GROUPS;
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < PRE_CHUNKS * PRE_GROUPS / 64; ++t) m = fmaxf(m, g[t * 64 + lane]);
+    for (int t = 0; t < pre_chunks * PRE_GROUPS / 64; ++t) m = fmaxf(m, g[t * 64 + lane]);
     const uint64_t sorted = wave_sort_desc((uint64_t)f32_orderable(m) << 32);
     const uint64_t kth = shfl_u64(sorted, KP - 1);
     if (lane == 0) thr[q] = orderable_f32((uint32_t)(kth >> 32));
@@ -399,15 +399,19 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     hipError_t e;
     const float* thr = nullptr;
     // (a handful of queries: the chunks warm their thresholds up themselves — cheaper than two more launches)
-    if (a.thr_init && n_tiles >= 8 * PRE_CHUNKS && a.nq > SMALL_NQ) {
-        static bool pattr = false;
-        if (!pattr) { (void)hipFuncSetAttribute((const void*)search_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES); pattr = true; }
-        float* gmax = a.cand_scores;                   // [nq_pad128][PRE_CHUNKS][PRE_GROUPS], dead before the sweep writes
-        hipLaunchKernelGGL(search_prepass_kernel, dim3(PRE_CHUNKS * q_tiles), dim3(256), GEMM_SMEM_BYTES, s, a, q_tiles,
-                           n_tiles / PRE_CHUNKS, gmax);
+    // sampled tiles: 32, or fewer on small shards (never more than one tile in eight: the pre-pass must stay small
+    // against the sweep — an 8-way shard of the 100k index has 98 tiles)
+    int pre_chunks = PRE_CHUNKS;
+    while (pre_chunks > 8 && n_tiles < 8 * pre_chunks) pre_chunks /= 2;
+    if (a.thr_init && n_tiles >= 8 * pre_chunks && a.nq > SMALL_NQ) {
+        static unsigned long long pattr = 0;    // bit d: set on device d
+        set_max_dynamic_lds((const void*)search_prepass_kernel, GEMM_SMEM_BYTES, pattr);
+        float* gmax = a.cand_scores;                   // [nq_pad128][pre_chunks][PRE_GROUPS], dead before the sweep writes
+        hipLaunchKernelGGL(search_prepass_kernel, dim3(pre_chunks * q_tiles), dim3(256), GEMM_SMEM_BYTES, s, a, q_tiles,
+                           n_tiles / pre_chunks, pre_chunks, gmax);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(search_thr_kernel<KP>, dim3(q_tiles * 32), dim3(256), 0, s, (const float*)gmax, q_tiles * 128,
-                           a.thr_init);
+                           pre_chunks, a.thr_init);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         thr = a.thr_init;
     }
