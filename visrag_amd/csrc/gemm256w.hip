@@ -142,20 +142,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile("" : "+v"(pA[st][kk]), "+v"(pW[st][kk]));
         }
 
-    W_FOR_EACH_ACC(W_ZERO)
-
     bf16x8 a0[8], w0[NJ], a1[8], w1[NJ];
     int m0, n0, split;
     coords(my_first, m0, n0, split);
     unsigned curA = tile_off_a(m0, split), curW = tile_off_w(n0, split);
 
-    // ---- prologue (first tile only): K-steps 0 and 1 in flight, k-half-0 fragments of step 0 requested
+    // ---- prologue: K-steps 0 and 1 in flight, the accumulators zeroed under their latency (256 register writes:
+    //      half a microsecond), k-half-0 fragments of step 0 requested
     {
         const unsigned k1 = nk > 1 ? (unsigned)(GEMM_BK * 2) : W_OOB;
 #pragma unroll
         for (int d = 0; d < NR; ++d) dma(0, d, lofA + curA, lofW + curW);
 #pragma unroll
         for (int d = 0; d < NR; ++d) dma(1, d, lofA + curA + k1, lofW + curW + k1);
+        W_FOR_EACH_ACC(W_ZERO)
         if constexpr (NJ == 8) VR_WAIT_VM_BARRIER(16); else VR_WAIT_VM_BARRIER(14);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) w0[j] = pW[0][0][j * 128];

@@ -163,13 +163,13 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
                 asm volatile("" : "+v"(pA[st][kk]), "+v"(pW[st][kk]));
             }
 
-        W_FOR_EACH_ACC(W_ZERO)
         bf16x8 a0[8], w0[8], a1[8], w1[8];
         {   // prologue: K-steps 0 and 1 of the first tile in flight, k-half-0 fragments of step 0 requested
 #pragma unroll
             for (int d = 0; d < NR; ++d) dma(0, d, lof, lof);
 #pragma unroll
             for (int d = 0; d < NR; ++d) dma(1, d, lof + (unsigned)(GEMM_BK * 2), lof + (unsigned)(GEMM_BK * 2));
+            W_FOR_EACH_ACC(W_ZERO)                              // (under the loads' latency)
             VR_WAIT_VM_BARRIER(16);
 #pragma unroll
             for (int j = 0; j < 8; ++j) w0[j] = pW[0][0][j * 128];
