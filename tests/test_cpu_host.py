@@ -27,6 +27,12 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    # ... and the same for the generator's header
+    ghdr = open(os.path.join(ROOT, "include", "visrag_gen.h")).read()
+    gdecl = set(re.findall(r"\b(vg_[a-z0-9_]+)\s*\(", ghdr))
+    for name in sorted(gdecl):
+        assert hasattr(lib, name), f"{name} declared in visrag_gen.h but not exported"
+    assert gdecl == set(_lib.GEN_SIGNATURES), gdecl ^ set(_lib.GEN_SIGNATURES)
     assert lib.vr_version().startswith(b"visrag_hip")
 
 
@@ -229,3 +235,20 @@ def test_build_flags_compiler_use_of_accumulation_registers():
     spill = ok + "\n\tv_accvgpr_write_b32 a17, v1 ; the compiler parking a VGPR\n"
     assert agpr_violations(spill) == ["v_accvgpr_write_b32 a17, v1 ; the compiler parking a VGPR"]
     assert AGPR_CHECKED <= set(SOURCES) and {"gemm256w.hip", "search256w.hip"} <= AGPR_CHECKED
+
+
+def test_evisrag_rope_index_layout():
+    """positions of a prompt with two images (Qwen2.5-VL get_rope_index for stills): text runs all three axes
+    together, an image pins the temporal axis and walks its grid, text resumes past the largest position."""
+    from visrag_amd.evisrag import rope_index
+    IMG = 9
+    ids = [1, 2, 3] + [IMG] * 6 + [4] + [IMG] * 4 + [5, 6]
+    pos = rope_index(ids, IMG, [(2, 3), (2, 2)])
+    assert pos[:, :3].tolist() == [[0, 1, 2]] * 3
+    assert pos[0, 3:9].tolist() == [3] * 6 and pos[1, 3:9].tolist() == [3, 3, 3, 4, 4, 4] and pos[2, 3:9].tolist() == [3, 4, 5, 3, 4, 5]
+    assert pos[:, 9].tolist() == [6, 6, 6]                       # 3 + max(2, 3)
+    assert pos[0, 10:14].tolist() == [7] * 4 and pos[1, 10:14].tolist() == [7, 7, 8, 8] and pos[2, 10:14].tolist() == [7, 8, 7, 8]
+    assert pos[:, 14:].tolist() == [[9, 10]] * 3                 # 7 + max(2, 2)
+    import pytest
+    with pytest.raises(ValueError):
+        rope_index(ids, IMG, [(2, 3)])

@@ -28,6 +28,14 @@ class VRConfig(C.Structure):
     ]
 
 
+class VGConfig(C.Structure):       # vg_config_t (include/visrag_gen.h)
+    _fields_ = [
+        ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+        ("intermediate_size", C.c_int32), ("vocab_size", C.c_int32), ("max_len", C.c_int32), ("max_prefill", C.c_int32),
+        ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float), ("mrope_section", C.c_int32 * 3),
+    ]
+
+
 class VisragHipError(RuntimeError):
     pass
 
@@ -65,6 +73,18 @@ SIGNATURES = {
     "vr_op_attention": (C.c_int, [C.c_int, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32,
                                   _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
 }
+# every symbol include/visrag_gen.h declares (the EVisRAG generator's language model)
+GEN_SIGNATURES = {
+    "vg_create": (C.c_int, [C.c_int, C.POINTER(VGConfig), C.POINTER(_vp)]),
+    "vg_destroy": (C.c_int, [_vp]),
+    "vg_load_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i32, _i32, _i32]),
+    "vg_finalize": (C.c_int, [_vp]),
+    "vg_prefill": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "vg_sample": (C.c_int, [_vp, _f32, _f32, C.c_uint64, _i32, C.POINTER(_i32), _vp]),
+    "vg_decode": (C.c_int, [_vp, _i32, C.POINTER(_i32), _vp]),
+    "vg_logits": (C.c_int, [_vp, _vp, _vp]),
+    "vg_cache_len": (C.c_int, [_vp, C.POINTER(_i32)]),
+}
 
 
 def load(path: Optional[str] = None) -> C.CDLL:
@@ -85,7 +105,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     # give torch a second one — streams and device pointers would not be shared).
     import torch  # noqa: F401
     lib = C.CDLL(p)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(GEN_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

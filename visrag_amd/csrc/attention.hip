@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
     if (qs >= q_len || kv_len <= 0) return;
 
     const bf16_t* qbase = (const bf16_t*)p.q + (size_t)(p.q_shared ? 0 : q_row0) * p.ldq + h * HD;
-    const bf16_t* kbase = (const bf16_t*)p.k + (size_t)kv0 * p.ldk + h * HD;
-    const bf16_t* vbase = (const bf16_t*)p.v + (size_t)kv0 * p.ldv + h * HD;
+    const int hkv = p.kv_group > 1 ? h / p.kv_group : h;          // grouped-query attention: K/V head of this query head
+    const bf16_t* kbase = (const bf16_t*)p.k + (size_t)kv0 * p.ldk + hkv * HD;
+    const bf16_t* vbase = (const bf16_t*)p.v + (size_t)kv0 * p.ldv + hkv * HD;
     // (wave-uniform: everything above derives from blockIdx and kernel arguments)
     const auto krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, ((kv_len - 1) * p.ldk + HD) * 2, 0x00020000);
     const auto vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, ((kv_len - 1) * p.ldv + HD) * 2, 0x00020000);

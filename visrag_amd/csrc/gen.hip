@@ -1,0 +1,360 @@
+// Host side of the EVisRAG generator's language model in libvisrag_hip.so: the C ABI of include/visrag_gen.h.
+// Reference boundary: src/evisrag/predict.py:112-123,147 (vllm.LLM / SamplingParams / llm.generate; vLLM itself is not
+// vendored).  Architecture: the Qwen2.5-VL text decoder — per layer RMSNorm, q/k/v projections with bias, multimodal
+// RoPE, grouped-query causal attention over a KV cache, o projection, RMSNorm, SwiGLU MLP; final RMSNorm + lm_head
+// (HF modeling_qwen2_5_vl.py:602-758; restated on the CPU in oracle/qwen_gen_oracle.py).
+//
+// Two paths through the same kernels of this library:
+//   prefill (M = prompt tokens): the one-wave-per-SIMD GEMMs with bias / residual / SwiGLU epilogues, fp32 residual
+//     stream, flash attention with a KV-group stride reading K / V straight from the cache;
+//   decode (M = 1): the same GEMM tile as a weight streamer — one 256-row tile of which row 0 is real, split over K so
+//     that ~250 workgroups pull the matrix through the chip; the fp32 partial rows are summed by the kernel that
+//     consumes them (mRoPE for q/k/v, the residual-adding RMSNorm for o / down).  ~15 GB of bf16 weights per token at
+//     7B: the HBM's pace sets the floor.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/visrag_gen.h"
+#include "engine_common.h"
+
+namespace {
+
+struct GenLayer {
+    Vec ln1, ln2;
+    Linear qkv, o, gu, down;
+    int parts_w = 0, parts_b = 0, parts_gu = 0;
+};
+
+constexpr int GEN_KS_MAX = 64;      // split-K planes of the decode path
+
+}  // namespace
+
+struct vg_model_s {
+    int device = 0;
+    vg_config_t c{};
+    bool finalized = false;
+    int E = 0, H = 0, KV = 0, I = 0, V = 0, QKV = 0, QD = 0, KVD = 0;
+    DevBuf embed;
+    bool has_embed = false;
+    std::vector<GenLayer> layers;
+    Vec final_norm;
+    Linear lm_head;
+    DevBuf inv_freq;
+    std::vector<DevBuf> kc, vc;          // per layer [max_len][KVD] bf16
+    int len = 0;                         // rows of the cache in use
+    bool have_logits = false;
+    int Tcap = 0;
+    DevBuf w_h, w_xn, w_qkv, w_q, w_att, w_act, w_last, w_part, w_logits, w_ids, w_pos, w_cu, w_seen, w_tok, w_erows, w_emb;
+};
+
+static GemmArgs gen_gemm_args(const void* A, int lda, const Linear& L, int M, void* out, int ldo) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = L.w.p; a.ldw = L.k_pad; a.M = M; a.N = L.n_pad; a.K = L.k_pad;
+    a.bias = L.has_b ? L.b.as<float>() : nullptr;
+    a.out = out; a.ldo = ldo; a.alpha = 1.0f;
+    return a;
+}
+
+// decode: split K so that (256-column tiles) x splits fills the chip; every split keeps >= 2 K-steps
+static int choose_ksplit(int n, int k) {
+    const int tiles = (n + 255) / 256, nk = k / 64;
+    int best = 1;
+    for (int d = 2; d <= GEN_KS_MAX && d <= nk / 2; ++d)
+        if (nk % d == 0 && tiles * d <= 256) best = d;
+    return best;
+}
+
+extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out) {
+    if (!cfg || !out) return fail(VR_ERR_INVALID, "cfg/out is NULL");
+    const vg_config_t& c = *cfg;
+    if (c.num_heads <= 0 || c.hidden_size != c.num_heads * 128) return fail(VR_ERR_INVALID, "head_dim must be 128 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
+    if (c.num_kv_heads <= 0 || c.num_heads % c.num_kv_heads) return fail(VR_ERR_INVALID, "num_heads must be a multiple of num_kv_heads");
+    if (c.hidden_size % 256 || c.intermediate_size % 64 || c.vocab_size % 128) return fail(VR_ERR_INVALID, "hidden %% 256, intermediate %% 64, vocab %% 128 must be 0");
+    if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return fail(VR_ERR_INVALID, "mrope sections must add up to 64 channel pairs");
+    if (c.num_layers <= 0 || c.max_len <= 0 || c.max_prefill <= 0 || c.max_prefill > c.max_len) return fail(VR_ERR_INVALID, "bad layer / length settings");
+    VRCHK(set_dev(device_id));
+    vg_model_s* m = new vg_model_s();
+    m->device = device_id;
+    m->c = c;
+    m->E = c.hidden_size; m->H = c.num_heads; m->KV = c.num_kv_heads; m->I = c.intermediate_size; m->V = c.vocab_size;
+    m->QD = m->H * 128; m->KVD = m->KV * 128; m->QKV = m->QD + 2 * m->KVD;
+    m->layers.resize(c.num_layers);
+    m->kc.resize(c.num_layers);
+    m->vc.resize(c.num_layers);
+    *out = m;
+    auto bail = [&](int rc) { vg_destroy(m); *out = nullptr; return rc; };
+    // rotary frequencies exactly as the reference builds them: 1 / theta^(2p / 128) in fp32 (modeling_qwen2_5_vl.py:519-523)
+    std::vector<float> inv(64);
+    for (int p = 0; p < 64; ++p) inv[p] = 1.0f / powf(c.rope_theta, (float)(2 * p) / 128.0f);
+    int rc;
+    if ((rc = m->inv_freq.alloc(64 * 4)) != VR_OK) return bail(rc);
+    if (hipMemcpy(m->inv_freq.p, inv.data(), 64 * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(VR_ERR_HIP, "hipMemcpy failed"));
+    for (int l = 0; l < c.num_layers; ++l) {
+        if ((rc = m->kc[l].alloc((size_t)c.max_len * m->KVD * 2)) != VR_OK) return bail(rc);
+        if ((rc = m->vc[l].alloc((size_t)c.max_len * m->KVD * 2)) != VR_OK) return bail(rc);
+    }
+    const size_t T = (size_t)pad256(c.max_prefill);
+    m->Tcap = (int)T;
+    const size_t E = m->E;
+    struct { DevBuf* b; size_t bytes; } ws[] = {
+        {&m->w_h, T * E * 4}, {&m->w_xn, T * E * 2}, {&m->w_qkv, T * m->QKV * 2}, {&m->w_q, T * m->QD * 2},
+        {&m->w_att, T * m->QD * 2}, {&m->w_act, T * (size_t)pad128(m->I) * 2}, {&m->w_last, 256 * E * 2},
+        {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(m->QKV, E) * 4}, {&m->w_logits, (size_t)m->V * 4},
+        {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, 16}, {&m->w_seen, (size_t)(m->V + 31) / 32 * 4},
+        {&m->w_tok, 16}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4}};
+    for (auto& w : ws)
+        if ((rc = w.b->alloc(w.bytes)) != VR_OK) return bail(rc);
+    return VR_OK;
+}
+
+extern "C" int vg_destroy(vg_model_t m) {
+    if (!m) return VR_OK;
+    (void)hipSetDevice(m->device);
+    delete m;                           // DevBuf destructors release everything
+    return VR_OK;
+}
+
+extern "C" int vg_load_weight(vg_model_t m, const char* name_c, const void* data, const int64_t* shape, int32_t ndim,
+                              int32_t dtype, int32_t on_device) {
+    if (!m || !name_c || !data || !shape) return fail(VR_ERR_INVALID, "NULL argument");
+    if (dtype != VR_DTYPE_F32 && dtype != VR_DTYPE_BF16) return fail(VR_ERR_INVALID, "bad dtype %d", dtype);
+    VRCHK(set_dev(m->device));
+    const std::string name(name_c);
+    const int bf = dtype == VR_DTYPE_BF16;
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    const int E = m->E, I = m->I, V = m->V, QD = m->QD, KVD = m->KVD, QKV = m->QKV;
+    auto bad_shape = [&]() { return fail(VR_ERR_INVALID, "unexpected shape for %s", name_c); };
+    if (name.rfind("model.visual.", 0) == 0 || name.rfind("visual.", 0) == 0) return VR_OK;      // vision tower: not this library's yet
+    Staged st;
+    VRCHK(stage(data, numel * (bf ? 2 : 4), on_device, st));
+    const void* src = st.dev;
+    m->finalized = false;
+    const std::string pre = "model.language_model.";
+    if (name == pre + "embed_tokens.weight") {
+        if (!shape_is(shape, ndim, {V, E})) return bad_shape();
+        VRCHK(m->embed.alloc(numel * 2));
+        HIPCHK(launch_pack_weight(src, bf, V, E, E, 0, m->embed.p, E, V, 0, 0, 0));
+        HIPCHK(hipDeviceSynchronize());
+        m->has_embed = true;
+        return VR_OK;
+    }
+    if (name == pre + "norm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(m->final_norm, src, bf, E, E); }
+    if (name == "lm_head.weight") { if (!shape_is(shape, ndim, {V, E})) return bad_shape(); return load_linear_part(m->lm_head, V, E, src, bf, V, E, 0, V, 0, 0); }
+    if (name.rfind(pre + "layers.", 0) == 0) {
+        int n = -1, off = 0;
+        if (sscanf(name.c_str(), "model.language_model.layers.%d.%n", &n, &off) < 1) return fail(VR_ERR_INVALID, "bad key %s", name_c);
+        if (n < 0 || n >= m->c.num_layers) return fail(VR_ERR_INVALID, "layer index %d out of range", n);
+        const std::string sub = name.substr(off);
+        GenLayer& l = m->layers[n];
+        if (sub == "input_layernorm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(l.ln1, src, bf, E, E); }
+        if (sub == "post_attention_layernorm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(l.ln2, src, bf, E, E); }
+        // q | k | v stacked into one [QKV][E] matrix (one GEMM), biases likewise
+        static const char* pn[3] = {"self_attn.q_proj.", "self_attn.k_proj.", "self_attn.v_proj."};
+        for (int part = 0; part < 3; ++part) {
+            const int rows = part == 0 ? QD : KVD, roff = part == 0 ? 0 : (part == 1 ? QD : QD + KVD);
+            if (sub == std::string(pn[part]) + "weight") {
+                if (!shape_is(shape, ndim, {rows, E})) return bad_shape();
+                l.parts_w |= 1 << part;
+                return load_linear_part(l.qkv, QKV, E, src, bf, rows, E, 0, rows, 0, roff);
+            }
+            if (sub == std::string(pn[part]) + "bias") {
+                if (numel != (size_t)rows) return bad_shape();
+                l.parts_b |= 1 << part;
+                return load_bias_part(l.qkv, QKV, src, bf, rows, roff);
+            }
+        }
+        if (sub == "self_attn.o_proj.weight") { if (!shape_is(shape, ndim, {E, QD})) return bad_shape(); return load_linear_part(l.o, E, QD, src, bf, E, QD, 0, E, 0, 0); }
+        if (sub == "mlp.gate_proj.weight" || sub == "mlp.up_proj.weight") {
+            if (!shape_is(shape, ndim, {I, E})) return bad_shape();
+            const int up = sub == "mlp.up_proj.weight";
+            l.parts_gu |= 1 << up;
+            return load_linear_part(l.gu, 2 * I, E, src, bf, I, E, 0, 16, 32, up * 16);     // 16-row [gate | up] interleave (EPI_SWIGLU)
+        }
+        if (sub == "mlp.down_proj.weight") { if (!shape_is(shape, ndim, {E, I})) return bad_shape(); return load_linear_part(l.down, E, I, src, bf, E, I, 0, E, 0, 0); }
+        return fail(VR_ERR_INVALID, "unknown decoder key %s", name_c);
+    }
+    return fail(VR_ERR_INVALID, "unknown key %s", name_c);
+}
+
+extern "C" int vg_finalize(vg_model_t m) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    if (!m->has_embed || !m->final_norm.ok || !m->lm_head.has_w) return fail(VR_ERR_STATE, "embed_tokens / norm / lm_head missing");
+    for (size_t i = 0; i < m->layers.size(); ++i) {
+        const GenLayer& l = m->layers[i];
+        if (!l.ln1.ok || !l.ln2.ok || l.parts_w != 7 || l.parts_b != 7 || l.parts_gu != 3 || !l.o.has_w || !l.down.has_w)
+            return fail(VR_ERR_STATE, "layer %zu is incomplete", i);
+    }
+    m->finalized = true;
+    return VR_OK;
+}
+
+// one decoder layer over T rows that already sit (normalised, bf16) in w_xn; cache rows [len, len + T)
+static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next_norm, hipStream_t s) {
+    const vg_config_t& c = m->c;
+    GenLayer& L = m->layers[l];
+    const int E = m->E, QD = m->QD, QKV = m->QKV, Ip = pad128(m->I);
+    float* h = m->w_h.as<float>();
+    float* part = m->w_part.as<float>();
+    int* cu = m->w_cu.as<int>();
+    // ---- q | k | v
+    if (decode) {
+        GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, T, part, QKV);
+        a.bias = nullptr;
+        a.ksplit = choose_ksplit(QKV, E);
+        a.split_stride = (size_t)QKV;
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
+        HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV, L.qkv.b.as<float>(), QKV, T, m->H, m->KV, m->w_pos.as<int>(),
+                                  m->Tcap, c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD,
+                                  m->kc[l].p, m->vc[l].p, m->KVD, m->len, cu + 2, s));
+    } else {
+        GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, T, m->w_qkv.p, QKV);
+        HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s));
+        HIPCHK(launch_mrope_cache(m->w_qkv.p, nullptr, 0, 0, nullptr, QKV, T, m->H, m->KV, m->w_pos.as<int>(), m->Tcap,
+                                  c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD, m->kc[l].p,
+                                  m->vc[l].p, m->KVD, m->len, cu + 2, s));
+    }
+    // ---- grouped-query attention over the cache (prefill: causal within the prompt; decode: the new row sees all)
+    {
+        AttnArgs a{};
+        a.q = m->w_q.p; a.ldq = QD; a.k = m->kc[l].p; a.ldk = m->KVD; a.v = m->vc[l].p; a.ldv = m->KVD;
+        a.out = m->w_att.p; a.ldo = QD; a.cu_q = cu; a.cu_kv = cu + 2;
+        a.B = 1; a.heads = m->H; a.head_dim = 128; a.max_q = T; a.causal = decode ? 0 : 1; a.q_shared = 0;
+        a.scale = 1.0f / sqrtf(128.0f);
+        a.kv_group = m->H / m->KV;
+        HIPCHK(launch_attention(a, s));
+    }
+    // ---- o projection + residual, post-attention norm
+    if (decode) {
+        GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, T, part, E);
+        a.ksplit = choose_ksplit(E, QD);
+        a.split_stride = (size_t)E;
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
+        HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E, E, 1.0f, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
+    } else {
+        GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, T, h, E);
+        a.resid = h;
+        HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
+        HIPCHK(launch_rmsnorm(h, T, E, E, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
+    }
+    // ---- SwiGLU MLP + residual; the next layer's (or the final) norm closes the layer
+    { GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.gu, T, m->w_act.p, Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
+    if (decode) {
+        GemmArgs a = gen_gemm_args(m->w_act.p, Ip, L.down, T, part, E);
+        a.ksplit = choose_ksplit(E, L.down.k_pad);
+        a.split_stride = (size_t)E;
+        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
+        HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E, E, 1.0f, next_norm, c.rms_norm_eps, m->w_xn.p, E, s));
+    } else {
+        GemmArgs a = gen_gemm_args(m->w_act.p, Ip, L.down, T, h, E);
+        a.resid = h;
+        HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
+        if (l + 1 < (int)m->layers.size()) HIPCHK(launch_rmsnorm(h, T, E, E, next_norm, c.rms_norm_eps, m->w_xn.p, E, s));
+    }
+    return VR_OK;
+}
+
+// final norm of one row (already in w_xn row 0 when `normed`) + lm_head -> w_logits
+static int gen_head(vg_model_s* m, const float* h_row, bool normed, hipStream_t s) {
+    const int E = m->E;
+    const void* A = m->w_xn.p;
+    if (!normed) {
+        HIPCHK(launch_rmsnorm(h_row, 1, E, E, m->final_norm.v.as<float>(), m->c.rms_norm_eps, m->w_last.p, E, s));
+        A = m->w_last.p;
+    }
+    GemmArgs a = gen_gemm_args(A, E, m->lm_head, 1, m->w_logits.p, m->lm_head.n_pad);
+    HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
+    m->have_logits = true;
+    return VR_OK;
+}
+
+extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int32_t* embed_rows, const float* embeds,
+                          int32_t n_embed, const int32_t* pos3, void* stream) {
+    if (!m || !ids || !pos3) return fail(VR_ERR_INVALID, "NULL argument");
+    if (!m->finalized) return fail(VR_ERR_STATE, "vg_finalize has not succeeded");
+    if (T <= 0 || T > m->c.max_prefill) return fail(VR_ERR_CAPACITY, "%d prompt tokens (max_prefill %d)", T, m->c.max_prefill);
+    if (n_embed < 0 || n_embed > T || (n_embed > 0 && (!embed_rows || !embeds))) return fail(VR_ERR_INVALID, "bad embedding overrides");
+    for (int i = 0; i < T; ++i)
+        if (ids[i] < 0 || ids[i] >= m->V) return fail(VR_ERR_INVALID, "token id %d out of range", ids[i]);
+    for (int i = 0; i < n_embed; ++i)
+        if (embed_rows[i] < 0 || embed_rows[i] >= T) return fail(VR_ERR_INVALID, "embedding row %d out of range", embed_rows[i]);
+    VRCHK(set_dev(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E;
+    m->len = 0;
+    m->have_logits = false;
+    HIPCHK(hipMemsetAsync(m->w_seen.p, 0, m->w_seen.bytes, s));
+    HIPCHK(hipMemcpyAsync(m->w_ids.p, ids, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    for (int c = 0; c < 3; ++c)
+        HIPCHK(hipMemcpyAsync(m->w_pos.as<int>() + (size_t)c * m->Tcap, pos3 + (size_t)c * T, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    const int cu_q[2] = {0, T};
+    HIPCHK(hipMemcpyAsync(m->w_cu.p, cu_q, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_mark_seen(m->w_ids.as<int>(), T, m->w_seen.as<unsigned>(), m->V, s));
+    HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
+    if (n_embed > 0) {
+        HIPCHK(hipMemcpyAsync(m->w_erows.p, embed_rows, (size_t)n_embed * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->w_emb.p, embeds, (size_t)n_embed * E * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(launch_scatter_rows(m->w_emb.as<float>(), m->w_erows.as<int>(), n_embed, E, m->w_h.as<float>(), E, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));            // the host buffers above may go away after the call
+    HIPCHK(launch_rmsnorm(m->w_h.as<float>(), T, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
+    const int nl = (int)m->layers.size();
+    for (int l = 0; l < nl; ++l)
+        VRCHK(gen_layer(m, l, T, false, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : nullptr, s));
+    m->len = T;
+    return gen_head(m, m->w_h.as<float>() + (size_t)(T - 1) * E, false, s);
+}
+
+extern "C" int vg_decode(vg_model_t m, int32_t token, const int32_t pos[3], void* stream) {
+    if (!m || !pos) return fail(VR_ERR_INVALID, "NULL argument");
+    if (!m->finalized || m->len <= 0) return fail(VR_ERR_STATE, "no sequence in progress (vg_prefill first)");
+    if (m->len >= m->c.max_len) return fail(VR_ERR_CAPACITY, "KV cache is full (%d rows)", m->c.max_len);
+    if (token < 0 || token >= m->V) return fail(VR_ERR_INVALID, "token id %d out of range", token);
+    VRCHK(set_dev(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->E;
+    // one token: id, its three positions and cu_q = {0, 1} travel as one small pinned-free copy each (a few bytes)
+    const int one[2] = {0, 1};
+    HIPCHK(hipMemcpyAsync(m->w_ids.p, &token, 4, hipMemcpyHostToDevice, s));
+    for (int c = 0; c < 3; ++c)
+        HIPCHK(hipMemcpyAsync(m->w_pos.as<int>() + (size_t)c * m->Tcap, pos + c, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->w_cu.p, one, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_embed_gather(m->w_ids.as<int>(), 1, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
+    HIPCHK(launch_rmsnorm(m->w_h.as<float>(), 1, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
+    const int nl = (int)m->layers.size();
+    for (int l = 0; l < nl; ++l)
+        VRCHK(gen_layer(m, l, 1, true, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : m->final_norm.v.as<float>(), s));
+    m->len += 1;
+    return gen_head(m, nullptr, true, s);
+}
+
+extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penalty, uint64_t seed, int32_t step,
+                         int32_t* token_out, void* stream) {
+    if (!m || !token_out) return fail(VR_ERR_INVALID, "NULL argument");
+    if (!m->have_logits) return fail(VR_ERR_STATE, "no logits yet (vg_prefill / vg_decode first)");
+    if (!(repetition_penalty > 0.f) || temperature < 0.f) return fail(VR_ERR_INVALID, "bad sampling parameters");
+    VRCHK(set_dev(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(launch_sample(m->w_logits.as<float>(), m->V, m->w_seen.as<unsigned>(), repetition_penalty, temperature, seed,
+                         (unsigned)step, m->w_tok.as<int>(), s));
+    HIPCHK(hipMemcpyAsync(token_out, m->w_tok.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return VR_OK;
+}
+
+extern "C" int vg_logits(vg_model_t m, float* out, void* stream) {
+    if (!m || !out) return fail(VR_ERR_INVALID, "NULL argument");
+    if (!m->have_logits) return fail(VR_ERR_STATE, "no logits yet");
+    VRCHK(set_dev(m->device));
+    HIPCHK(hipMemcpyAsync(out, m->w_logits.p, (size_t)m->V * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VR_OK;
+}
+
+extern "C" int vg_cache_len(vg_model_t m, int32_t* len) {
+    if (!m || !len) return fail(VR_ERR_INVALID, "NULL argument");
+    *len = m->len;
+    return VR_OK;
+}

@@ -1,0 +1,152 @@
+// Small kernels of the EVisRAG generator's language model (gen.hip): multimodal RoPE + KV-cache append, and
+// next-token selection (repetition penalty, temperature via the Gumbel-max trick, argmax).
+// Arithmetic restated from the HuggingFace Qwen2.5-VL implementation (see oracle/qwen_gen_oracle.py for the
+// file:line map); the reference itself delegates it to vLLM (src/evisrag/predict.py:112-123,147).
+// Roofline: both are HBM/latency bound and tiny (a few KiB to ~600 KiB per call).
+#include "common.h"
+#include "kernels.h"
+
+namespace vr {
+
+namespace {
+
+// 64-bit counter hash -> uniform in (0, 1): the sampling noise of token `idx` at decode step `step`
+__device__ __forceinline__ float gumbel_noise(unsigned long long seed, unsigned step, unsigned idx) {
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)step << 32 | idx);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    const float u = ((float)(x >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    return -__logf(-__logf(u));
+}
+
+}  // namespace
+
+// One wave per (token, head slot): slots [0, H) rotate the query heads in place, [H, H + KV) rotate the key
+// heads into the K cache, [H + KV, H + 2 KV) copy the value heads into the V cache.  head_dim 128: lane p holds
+// the rotate-half pair (p, p + 64).  Multimodal RoPE (modeling_qwen2_5_vl.py:486-538, 557-599): the pair's angle is
+// pos[c] * theta^(-2p/128) with the position component c = temporal / height / width chosen by p's section.
+//   src: bf16 qkv rows [T][ld] (bias already added by the GEMM), or parts != null: fp32 split-K partial
+//   planes [n_parts][plane_stride] of the same rows + bias (decode), summed here in a fixed order.
+__global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restrict__ src, const float* __restrict__ parts,
+                                                          int n_parts, size_t plane_stride, const float* __restrict__ bias,
+                                                          int ld, int T, int H, int KV, const int* __restrict__ pos3,
+                                                          int pos_stride, int sec_t, int sec_h, const float* __restrict__ inv_freq,
+                                                          bf16_t* __restrict__ q_out, int ldq, bf16_t* __restrict__ k_cache,
+                                                          bf16_t* __restrict__ v_cache, int ld_cache, int cache_row0,
+                                                          int* __restrict__ cu_kv) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slots = H + 2 * KV;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cu_kv) { cu_kv[0] = 0; cu_kv[1] = cache_row0 + T; }
+    if (slot >= T * slots) return;
+    const int t = slot / slots, hs = slot % slots;
+    const int col = hs * 128;
+    float x1, x2;
+    if (parts) {
+        x1 = bias ? bias[col + lane] : 0.f;
+        x2 = bias ? bias[col + 64 + lane] : 0.f;
+        for (int s = 0; s < n_parts; ++s) {
+            const float* row = parts + (size_t)s * plane_stride + (size_t)t * ld + col;
+            x1 += row[lane];
+            x2 += row[64 + lane];
+        }
+    } else {
+        const bf16_t* row = src + (size_t)t * ld + col;
+        x1 = bf2f(row[lane]);
+        x2 = bf2f(row[64 + lane]);
+    }
+    if (hs < H + KV) {
+        const int c = lane < sec_t ? 0 : (lane < sec_t + sec_h ? 1 : 2);
+        const float pos = (float)pos3[c * pos_stride + t];
+        const float ang = pos * inv_freq[lane];                                          // inv_freq[p] = theta^(-2p/128), host-made
+        const float cs = cosf(ang), sn = sinf(ang);
+        const float r1 = x1 * cs - x2 * sn, r2 = x2 * cs + x1 * sn;                      // x*cos + rotate_half(x)*sin
+        x1 = r1; x2 = r2;
+    }
+    bf16_t* dst;
+    if (hs < H) dst = q_out + (size_t)t * ldq + col;
+    else if (hs < H + KV) dst = k_cache + (size_t)(cache_row0 + t) * ld_cache + (hs - H) * 128;
+    else dst = v_cache + (size_t)(cache_row0 + t) * ld_cache + (hs - H - KV) * 128;
+    dst[lane] = f2bf(x1);
+    dst[64 + lane] = f2bf(x2);
+}
+
+hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_parts, size_t plane_stride, const float* bias,
+                              int ld, int T, int H, int KV, const int* pos3, int pos_stride, int sec_t, int sec_h,
+                              const float* inv_freq, void* q_out, int ldq, void* k_cache, void* v_cache, int ld_cache,
+                              int cache_row0, int* cu_kv, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    const int slots = T * (H + 2 * KV);
+    hipLaunchKernelGGL(mrope_cache_kernel, dim3((slots + 3) / 4), dim3(256), 0, s, (const bf16_t*)src_bf16, parts, n_parts,
+                       plane_stride, bias, ld, T, H, KV, pos3, pos_stride, sec_t, sec_h, inv_freq, (bf16_t*)q_out, ldq,
+                       (bf16_t*)k_cache, (bf16_t*)v_cache, ld_cache, cache_row0, cu_kv);
+    return hipGetLastError();
+}
+
+// seen[id / 32] |= 1 << (id % 32) for the prompt's token ids (the repetition penalty covers prompt and output)
+__global__ void mark_seen_kernel(const int* __restrict__ ids, int n, unsigned* __restrict__ seen, int vocab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ids[i] >= 0 && ids[i] < vocab) atomicOr(&seen[ids[i] >> 5], 1u << (ids[i] & 31));
+}
+hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_seen_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids, n, seen, vocab);
+    return hipGetLastError();
+}
+
+// Next token from one row of logits: repetition penalty on the seen ids (logit > 0 ? / penalty : * penalty — vLLM's
+// and HF's RepetitionPenaltyLogitsProcessor), then argmax of logit / temperature + Gumbel noise (an exact sample of
+// softmax(logit / temperature); temperature 0 = plain argmax, ties to the lowest id like torch.argmax).  One
+// workgroup; writes the token, marks it seen.
+__global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ logits, int vocab, unsigned* __restrict__ seen,
+                                                      float penalty, float temperature, unsigned long long seed,
+                                                      unsigned step, int* __restrict__ token_out) {
+    __shared__ unsigned long long best[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float inv_t = temperature > 0.f ? 1.0f / temperature : 1.0f;
+    unsigned long long key = 0ull;
+    for (int i = tid; i < vocab; i += 1024) {
+        float l = logits[i];
+        if ((seen[i >> 5] >> (i & 31)) & 1u) l = l > 0.f ? l / penalty : l * penalty;
+        float sc = l * inv_t;
+        if (temperature > 0.f) sc += gumbel_noise(seed, step, (unsigned)i);
+        unsigned b = __float_as_uint(sc);
+        b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                 // order-preserving map of the float
+        const unsigned long long k = ((unsigned long long)b << 32) | (unsigned)(~(unsigned)i);   // ties: lowest id wins
+        key = k > key ? k : key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off, 64);
+        key = o > key ? o : key;
+    }
+    if (lane == 0) best[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long k = best[0];
+        for (int w = 1; w < 16; ++w) k = best[w] > k ? best[w] : k;
+        const int tok = (int)(~(unsigned)(k & 0xFFFFFFFFull));
+        *token_out = tok;
+        seen[tok >> 5] |= 1u << (tok & 31);
+    }
+}
+hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
+                         unsigned long long seed, unsigned step, int* token_out, hipStream_t s) {
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, logits, vocab, seen, penalty, temperature, seed, step, token_out);
+    return hipGetLastError();
+}
+
+// rows[row_idx[i]][:] = src[i][:]  (image embeddings dropped into the prompt's embedding rows, fp32)
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ row_idx, int n, int dim,
+                                    float* __restrict__ dst, int ld) {
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) dst[(size_t)row_idx[i] * ld + c] = src[(size_t)i * dim + c];
+}
+hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int dim, float* dst, int ld, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(256), 0, s, src, row_idx, n, dim, dst, ld);
+    return hipGetLastError();
+}
+
+}  // namespace vr

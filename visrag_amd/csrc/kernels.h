@@ -63,8 +63,23 @@ struct AttnArgs {
     int B, heads, head_dim, max_q;
     int causal, q_shared;            // q_shared: q rows [0,max_q) are the same for every batch item
     float scale;
+    int kv_group;                    // grouped-query attention: query head h reads K/V head h / kv_group (0 or 1: one each)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---- EVisRAG generator (gen_kernels.hip) ---------------------------------------------------
+// multimodal RoPE on q (in place into q_out) and k (into the K cache at rows cache_row0 + t), v copied into the V
+// cache; head_dim 128; pos3 = [3][pos_stride] ints (temporal, height, width); inv_freq f32 [64]; source = bf16 qkv rows
+// or (parts != null) fp32 split-K planes + bias; cu_kv (optional) receives {0, cache_row0 + T}
+hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_parts, size_t plane_stride, const float* bias,
+                              int ld, int T, int H, int KV, const int* pos3, int pos_stride, int sec_t, int sec_h,
+                              const float* inv_freq, void* q_out, int ldq, void* k_cache, void* v_cache, int ld_cache,
+                              int cache_row0, int* cu_kv, hipStream_t s);
+hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hipStream_t s);
+// repetition penalty over the seen ids, temperature sampling (Gumbel-max; 0 = argmax), marks the chosen token seen
+hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
+                         unsigned long long seed, unsigned step, int* token_out, hipStream_t s);
+hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int dim, float* dst, int ld, hipStream_t s);
 
 // ---- elementwise / gather / pooling (misc.hip) ---------------------------------------------
 // Fused ToTensor/Normalize + patch-embed conv (patch_embed.hip): g carries the PERMUTED weight (k = ky*3P + kx*3 + c),

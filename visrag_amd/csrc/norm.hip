@@ -8,7 +8,7 @@
 
 namespace vr {
 
-constexpr int NORM_MAXV = 10;   // float4 per lane: rows up to 64*4*10 = 2560 columns
+constexpr int NORM_MAXV = 14;   // float4 per lane: rows up to 64*4*14 = 3584 columns (the generator's hidden size)
 
 template <bool RMS>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int rows, int dim, int ldx,

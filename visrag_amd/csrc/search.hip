@@ -176,7 +176,6 @@ __global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict
     if (q >= nq_pad) return;
     const float* g = gmax + (size_t)q * pre_chunks * PRE_GROUPS;
     float m = -INFINITY;
-#pragma unroll
     for (int t = 0; t < pre_chunks * PRE_GROUPS / 64; ++t) m = fmaxf(m, g[t * 64 + lane]);
     const uint64_t sorted = wave_sort_desc((uint64_t)f32_orderable(m) << 32);
     const uint64_t kth = shfl_u64(sorted, KP - 1);
