@@ -1,0 +1,123 @@
+// bf16 GEMM for M <= 16 rows: the generator's decode step, where a GEMM is a pass over the weights.
+//
+//   out[split][m][n] = A[m, Ks] * W[n, Ks]^T      (fp32 partial planes, summed by their consumer)
+//
+// The 256 x 256 tiles of the other kernels spend a K-step (64 k) on 128 MFMAs per wave of which one row in sixteen
+// is real, and stream their 32 KiB of weights per step at the pace of that arithmetic: 26 GB/s per CU, 1.6 TB/s
+// for the 7B decoder.  Here a workgroup owns 256 output columns and a K range, four waves x 64 columns, EIGHT
+// MFMAs per wave and K-step, and four LDS stages (32 KiB of W + 2 KiB of A each) keep three K-steps of LDS-DMA in
+// flight: ~100 KiB per CU against ~2 us of HBM latency, so the chip's 256 CUs can ask for more than the HBM
+// delivers.  Roofline: HBM (N * K * 2 bytes of weights per launch).
+//
+// LDS image and swizzle of gemm_core.h (16-byte chunk c of row r at chunk c ^ (r & 7)); every wave issues the same
+// nine loads per K-step (eight 8-row groups of its 64 W rows + one 8-row group of A — waves 2 and 3 repeat the
+// groups of waves 0 and 1) so one `vmcnt(18)` fits all; K-steps past the end point out of the descriptor's range.
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vr {
+
+namespace {
+
+constexpr int SK_STAGES = 4;
+constexpr int SK_W_BYTES = 256 * 128, SK_A_BYTES = 16 * 128;
+constexpr int SK_STAGE = SK_W_BYTES + SK_A_BYTES;
+constexpr int SK_SMEM = SK_STAGES * SK_STAGE;
+constexpr unsigned SK_OOB = 0x80000000u;
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (p.N + 255) / 256;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int split = blockIdx.x / tiles_n, tn = blockIdx.x - split * tiles_n;
+    const int n0 = tn * 256;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int Ks = p.K / ks, nk = Ks / GEMM_BK;
+
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + ((size_t)n0 * p.ldw + (size_t)split * Ks) * 2), 0,
+                                                         0x7FFFFFFF, 0x00020000);
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (size_t)split * Ks * 2), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned lchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
+    const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
+    const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
+    const unsigned rgW = (unsigned)p.ldw * 16u;
+    const unsigned sW0 = (unsigned)wave * 8u * rgW, sA0 = (unsigned)(wave & 1) * (unsigned)p.lda * 16u;
+    auto issue = [&](int kt) {                      // the 9 loads of K-step kt into stage kt % 4
+        char* st = smem + (kt & (SK_STAGES - 1)) * SK_STAGE;
+        const unsigned kb = kt < nk ? (unsigned)kt * (GEMM_BK * 2) : SK_OOB;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(st + wave * 8192 + d * 1024), 16, lofW + kb, sW0 + d * rgW, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(st + SK_W_BYTES + (wave & 1) * 1024), 16, lofA + kb, sA0, 0, 0);
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue(0); issue(1); issue(2);
+    const int ch0 = (fq ^ (fr & 7)) << 4, ch1 = ((4 + fq) ^ (fr & 7)) << 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        VR_WAIT_VM_BARRIER(18);                     // K-step kt has landed everywhere; everyone is done with stage (kt - 1) % 4
+        issue(kt + 3);
+        const char* st = smem + (kt & (SK_STAGES - 1)) * SK_STAGE;
+        const char* wr = st + (wave * 64 + fr) * 128;
+        const char* ar = st + SK_W_BYTES + fr * 128;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ar + ch0), a1 = *reinterpret_cast<const bf16x8*>(ar + ch1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wr + j * 2048 + ch0);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wr + j * 2048 + ch1);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a1, acc[j], 0, 0, 0);
+        }
+    }
+    // acc[j][r] = out[m = fr][n = n0 + wave*64 + j*16 + fq*4 + r]; bias rides with split 0
+    if (fr < p.M) {
+        float* out = (float*)p.out + (size_t)split * p.split_stride + (size_t)fr * p.ldo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wave * 64 + j * 16 + fq * 4;
+            if (n < p.N) {
+                f32x4 v = acc[j];
+                if (p.bias && split == 0) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                *reinterpret_cast<f32x4*>(out + n) = v;
+            }
+        }
+    }
+}
+
+// fp32 planes out[split][M][ldo]; M <= 16 (A and W rows readable up to 16 / the next multiple of 256), K % (ksplit * 64) == 0
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s) {
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    if (a.M <= 0) return hipSuccess;
+    if (a.M > 16 || a.N % 4 || a.K % (ks * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
+    const size_t tn = (a.N + 255) / 256;
+    if (tn * 256 * (size_t)a.ldw * 2 >= (1ull << 31) || 16 * (size_t)a.lda * 2 >= (1ull << 31)) return hipErrorInvalidValue;
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)gemm_skinny_kernel, SK_SMEM, attr);
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a);
+    return hipGetLastError();
+}
+
+// act[m][i] = silu(gate) * up from the fp32 partial planes of a gate/up GEMM whose W rows are interleaved in blocks
+// of 16 ([16 gate | 16 up | ...], EPI_SWIGLU's layout): gate of column i sits at (i / 16) * 32 + i % 16, up 16 further
+__global__ void swiglu_sum_kernel(const float* __restrict__ parts, int n_parts, size_t plane_stride, int ldp, int M, int I,
+                                  bf16_t* __restrict__ act, int lda) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (i >= I) return;
+    const size_t g = (size_t)m * ldp + (size_t)(i >> 4) * 32 + (i & 15);
+    float gate = 0.f, up = 0.f;
+    for (int sp = 0; sp < n_parts; ++sp) { gate += parts[sp * plane_stride + g]; up += parts[sp * plane_stride + g + 16]; }
+    act[(size_t)m * lda + i] = f2bf(gate / (1.0f + __expf(-gate)) * up);
+}
+hipError_t launch_swiglu_sum(const float* parts, int n_parts, size_t plane_stride, int ldp, int M, int I, void* act, int lda,
+                             hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(swiglu_sum_kernel, dim3((I + 255) / 256, M), dim3(256), 0, s, parts, n_parts, plane_stride, ldp, M, I,
+                       (bf16_t*)act, lda);
+    return hipGetLastError();
+}
+
+}  // namespace vr

@@ -7,10 +7,10 @@
 // Two paths through the same kernels of this library:
 //   prefill (M = prompt tokens): the one-wave-per-SIMD GEMMs with bias / residual / SwiGLU epilogues, fp32 residual
 //     stream, flash attention with a KV-group stride reading K / V straight from the cache;
-//   decode (M = 1): the same GEMM tile as a weight streamer — one 256-row tile of which row 0 is real, split over K so
-//     that ~250 workgroups pull the matrix through the chip; the fp32 partial rows are summed by the kernel that
-//     consumes them (mRoPE for q/k/v, the residual-adding RMSNorm for o / down).  ~15 GB of bf16 weights per token at
-//     7B: the HBM's pace sets the floor.
+//   decode (M = 1): every GEMM is one pass over its weights (gemm_skinny.hip: 256 columns x a K range per workgroup,
+//     four LDS stages of LDS-DMA, eight MFMAs per wave and K-step), split over K so that ~500 workgroups pull on the
+//     HBM; the fp32 partial rows are summed by the kernel that consumes them (mRoPE for q/k/v, SwiGLU for gate/up,
+//     the residual-adding RMSNorm for o / down).  ~14 GB of bf16 weights per token at 7B: the HBM sets the floor.
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -57,12 +57,13 @@ static GemmArgs gen_gemm_args(const void* A, int lda, const Linear& L, int M, vo
     return a;
 }
 
-// decode: split K so that (256-column tiles) x splits fills the chip; every split keeps >= 2 K-steps
+// decode (gemm_skinny.hip): split K so that (256-column tiles) x splits gives the chip about two workgroups per CU
+// to pull on; every split keeps >= 4 K-steps
 static int choose_ksplit(int n, int k) {
     const int tiles = (n + 255) / 256, nk = k / 64;
     int best = 1;
-    for (int d = 2; d <= GEN_KS_MAX && d <= nk / 2; ++d)
-        if (nk % d == 0 && tiles * d <= 256) best = d;
+    for (int d = 2; d <= GEN_KS_MAX && d <= nk / 4; ++d)
+        if (nk % d == 0 && tiles * d <= 512) best = d;
     return best;
 }
 
@@ -101,7 +102,7 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
     struct { DevBuf* b; size_t bytes; } ws[] = {
         {&m->w_h, T * E * 4}, {&m->w_xn, T * E * 2}, {&m->w_qkv, T * m->QKV * 2}, {&m->w_q, T * m->QD * 2},
         {&m->w_att, T * m->QD * 2}, {&m->w_act, T * (size_t)pad128(m->I) * 2}, {&m->w_last, 256 * E * 2},
-        {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(m->QKV, E) * 4}, {&m->w_logits, (size_t)m->V * 4},
+        {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(std::max<size_t>(m->QKV, E), (size_t)pad128(2 * m->I)) * 4}, {&m->w_logits, (size_t)m->V * 4},
         {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, 16}, {&m->w_seen, (size_t)(m->V + 31) / 32 * 4},
         {&m->w_tok, 16}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4}};
     for (auto& w : ws)
@@ -204,9 +205,9 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
         GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, T, part, QKV);
         a.bias = nullptr;
         a.ksplit = choose_ksplit(QKV, E);
-        a.split_stride = (size_t)QKV;
-        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
-        HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV, L.qkv.b.as<float>(), QKV, T, m->H, m->KV, m->w_pos.as<int>(),
+        a.split_stride = (size_t)QKV * T;
+        HIPCHK(launch_gemm_skinny(a, s));
+        HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV * T, L.qkv.b.as<float>(), QKV, T, m->H, m->KV, m->w_pos.as<int>(),
                                   m->Tcap, c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD,
                                   m->kc[l].p, m->vc[l].p, m->KVD, m->len, cu + 2, s));
     } else {
@@ -230,9 +231,9 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
     if (decode) {
         GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, T, part, E);
         a.ksplit = choose_ksplit(E, QD);
-        a.split_stride = (size_t)E;
-        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
-        HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E, E, 1.0f, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
+        a.split_stride = (size_t)E * T;
+        HIPCHK(launch_gemm_skinny(a, s));
+        HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E * T, E, 1.0f, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
     } else {
         GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, T, h, E);
         a.resid = h;
@@ -240,14 +241,20 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
         HIPCHK(launch_rmsnorm(h, T, E, E, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
     }
     // ---- SwiGLU MLP + residual; the next layer's (or the final) norm closes the layer
-    { GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.gu, T, m->w_act.p, Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
     if (decode) {
+        const int N2 = L.gu.n_pad;
+        GemmArgs g = gen_gemm_args(m->w_xn.p, E, L.gu, T, part, N2);
+        g.ksplit = choose_ksplit(N2, E);
+        g.split_stride = (size_t)N2 * T;
+        HIPCHK(launch_gemm_skinny(g, s));
+        HIPCHK(launch_swiglu_sum(part, g.ksplit, (size_t)N2 * T, N2, T, m->I, m->w_act.p, Ip, s));
         GemmArgs a = gen_gemm_args(m->w_act.p, Ip, L.down, T, part, E);
         a.ksplit = choose_ksplit(E, L.down.k_pad);
-        a.split_stride = (size_t)E;
-        HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
-        HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E, E, 1.0f, next_norm, c.rms_norm_eps, m->w_xn.p, E, s));
+        a.split_stride = (size_t)E * T;
+        HIPCHK(launch_gemm_skinny(a, s));
+        HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E * T, E, 1.0f, next_norm, c.rms_norm_eps, m->w_xn.p, E, s));
     } else {
+        { GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.gu, T, m->w_act.p, Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
         GemmArgs a = gen_gemm_args(m->w_act.p, Ip, L.down, T, h, E);
         a.resid = h;
         HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
@@ -265,7 +272,7 @@ static int gen_head(vg_model_s* m, const float* h_row, bool normed, hipStream_t 
         A = m->w_last.p;
     }
     GemmArgs a = gen_gemm_args(A, E, m->lm_head, 1, m->w_logits.p, m->lm_head.n_pad);
-    HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_256W, s));
+    HIPCHK(launch_gemm_skinny(a, s));
     m->have_logits = true;
     return VR_OK;
 }

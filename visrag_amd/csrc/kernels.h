@@ -40,6 +40,12 @@ bool gemm256w_fits(const GemmArgs& a, int tile_cols);   // its 32-bit LDS-DMA of
 // its 256x192 form: N % 192 == 0, EPI_RESID and EPI_F32 (incl. ksplit)
 hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
 
+// M <= 16 rows (gemm_skinny.hip): the decode step's weight streamer; fp32 planes out[split][M][ldo] (+ bias with split 0)
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s);
+// act = silu(gate) * up from the fp32 planes of a gate/up GEMM over 16-row interleaved weights
+hipError_t launch_swiglu_sum(const float* parts, int n_parts, size_t plane_stride, int ldp, int M, int I, void* act, int lda,
+                             hipStream_t s);
+
 // ---- norms (norm.hip) --------------------------------------------------------------------
 // x f32 [rows][ldx] (dim used) -> bf16 [rows][ldo]; columns [dim, ldo) are written as zero.
 hipError_t launch_layernorm(const float* x, int rows, int dim, int ldx, const float* w, const float* b,
