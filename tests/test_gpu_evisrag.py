@@ -112,6 +112,25 @@ def test_decode_step_equals_prefill_of_longer_prompt(setup):
     assert int(step.argmax()) == int(full.argmax())
 
 
+def test_decode_over_a_long_cache(setup):
+    """a cache longer than 128 rows: the decode step's attention runs as several KV ranges merged by their
+    log-sum-exps; against the oracle's full forward and against the engine's own prefill of the longer prompt"""
+    g, cfg, w, llm = setup
+    ids = np.random.default_rng(5).integers(0, cfg.vocab_size, 211).tolist()
+    o = QwenGenOracle(cfg, w)
+    idt = torch.tensor(ids)
+    ref = o.forward(o.embed(idt), torch.arange(len(ids))[None].expand(3, -1))[-1].numpy()
+    llm.prefill(ids[:-3])
+    for k in range(3, 0, -1):
+        llm.decode(ids[-k], len(ids) - k)
+    step = llm.logits()
+    llm.prefill(ids)
+    full = llm.logits()
+    scale = np.abs(ref).max()
+    assert np.abs(step - ref).max() < 2e-2 * scale and np.abs(full - ref).max() < 2e-2 * scale
+    assert np.abs(step - full).max() < 1e-2 * scale
+
+
 def test_sampling_kernel(setup):
     from visrag_amd.evisrag import SamplingParams
     g, cfg, w, llm = setup

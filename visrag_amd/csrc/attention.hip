@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
         float l = l_run[f];
         if constexpr (TAIL) l = __shfl(o[f][DFRAGS - 1][0], 32 + fr, 64);   // O^T[72][q]: lane (fq=2, fr=q), reg 0 (all lanes active here)
         if (q >= q_len) continue;
+        if (p.lse && fq == 0) p.lse[(size_t)(q_row0 + q) * p.heads + h] = m_run[f] + __log2f(l);     // sum_k 2^(s_k * sc) = 2^m * l
         const float inv = 1.0f / l;
         bf16_t* orow = (bf16_t*)p.out + (size_t)(q_row0 + q) * p.ldo + h * HD;
 #pragma unroll

@@ -11,6 +11,7 @@
 //     four LDS stages of LDS-DMA, eight MFMAs per wave and K-step), split over K so that ~500 workgroups pull on the
 //     HBM; the fp32 partial rows are summed by the kernel that consumes them (mRoPE for q/k/v, SwiGLU for gate/up,
 //     the residual-adding RMSNorm for o / down).  ~14 GB of bf16 weights per token at 7B: the HBM sets the floor.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -28,6 +29,7 @@ struct GenLayer {
 };
 
 constexpr int GEN_KS_MAX = 64;      // split-K planes of the decode path
+constexpr int GEN_ATT_SPLITS = 16;  // most KV ranges one decode step's attention is cut into
 
 }  // namespace
 
@@ -47,6 +49,8 @@ struct vg_model_s {
     bool have_logits = false;
     int Tcap = 0;
     DevBuf w_h, w_xn, w_qkv, w_q, w_att, w_act, w_last, w_part, w_logits, w_ids, w_pos, w_cu, w_seen, w_tok, w_erows, w_emb;
+    DevBuf w_attp, w_lse;               // decode: partial attention rows [GEN_ATT_SPLITS][QD] bf16 + their log-sum-exps
+    int dec_splits = 1;                 // KV ranges of the current decode step (w_cu: cu_q at [0..], cu_kv at [GEN_ATT_SPLITS + 1..])
 };
 
 static GemmArgs gen_gemm_args(const void* A, int lda, const Linear& L, int M, void* out, int ldo) {
@@ -103,7 +107,8 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
         {&m->w_h, T * E * 4}, {&m->w_xn, T * E * 2}, {&m->w_qkv, T * m->QKV * 2}, {&m->w_q, T * m->QD * 2},
         {&m->w_att, T * m->QD * 2}, {&m->w_act, T * (size_t)pad128(m->I) * 2}, {&m->w_last, 256 * E * 2},
         {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(std::max<size_t>(m->QKV, E), (size_t)pad128(2 * m->I)) * 4}, {&m->w_logits, (size_t)m->V * 4},
-        {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, 16}, {&m->w_seen, (size_t)(m->V + 31) / 32 * 4},
+        {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, (2 * GEN_ATT_SPLITS + 2) * 4},
+        {&m->w_attp, (size_t)GEN_ATT_SPLITS * m->QD * 2}, {&m->w_lse, (size_t)GEN_ATT_SPLITS * m->H * 4}, {&m->w_seen, (size_t)(m->V + 31) / 32 * 4},
         {&m->w_tok, 16}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4}};
     for (auto& w : ws)
         if ((rc = w.b->alloc(w.bytes)) != VR_OK) return bail(rc);
@@ -209,23 +214,33 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
         HIPCHK(launch_gemm_skinny(a, s));
         HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV * T, L.qkv.b.as<float>(), QKV, T, m->H, m->KV, m->w_pos.as<int>(),
                                   m->Tcap, c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD,
-                                  m->kc[l].p, m->vc[l].p, m->KVD, m->len, cu + 2, s));
+                                  m->kc[l].p, m->vc[l].p, m->KVD, m->len, nullptr, s));
     } else {
         GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, T, m->w_qkv.p, QKV);
         HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s));
         HIPCHK(launch_mrope_cache(m->w_qkv.p, nullptr, 0, 0, nullptr, QKV, T, m->H, m->KV, m->w_pos.as<int>(), m->Tcap,
                                   c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD, m->kc[l].p,
-                                  m->vc[l].p, m->KVD, m->len, cu + 2, s));
+                                  m->vc[l].p, m->KVD, m->len, nullptr, s));
     }
-    // ---- grouped-query attention over the cache (prefill: causal within the prompt; decode: the new row sees all)
+    // ---- grouped-query attention over the cache.  Prefill: causal within the prompt.  Decode: the new row sees the
+    //      whole cache; one query row x 28 heads would be 28 workgroups, so the cache is cut into dec_splits ranges
+    //      that run as independent "sequences" sharing the query row (q_shared), and a small kernel merges them by
+    //      their log-sum-exps.
     {
+        int* cu_kv = cu + GEN_ATT_SPLITS + 1;
         AttnArgs a{};
         a.q = m->w_q.p; a.ldq = QD; a.k = m->kc[l].p; a.ldk = m->KVD; a.v = m->vc[l].p; a.ldv = m->KVD;
-        a.out = m->w_att.p; a.ldo = QD; a.cu_q = cu; a.cu_kv = cu + 2;
-        a.B = 1; a.heads = m->H; a.head_dim = 128; a.max_q = T; a.causal = decode ? 0 : 1; a.q_shared = 0;
-        a.scale = 1.0f / sqrtf(128.0f);
-        a.kv_group = m->H / m->KV;
-        HIPCHK(launch_attention(a, s));
+        a.cu_q = cu; a.cu_kv = cu_kv;
+        a.heads = m->H; a.head_dim = 128; a.scale = 1.0f / sqrtf(128.0f); a.kv_group = m->H / m->KV;
+        if (decode && m->dec_splits > 1) {
+            a.out = m->w_attp.p; a.ldo = QD; a.B = m->dec_splits; a.max_q = 1; a.causal = 0; a.q_shared = 1;
+            a.lse = m->w_lse.as<float>();
+            HIPCHK(launch_attention(a, s));
+            HIPCHK(launch_attn_combine(m->w_attp.p, QD, m->w_lse.as<float>(), m->dec_splits, m->H, m->w_att.p, s));
+        } else {
+            a.out = m->w_att.p; a.ldo = QD; a.B = 1; a.max_q = T; a.causal = decode ? 0 : 1; a.q_shared = 0;
+            HIPCHK(launch_attention(a, s));
+        }
     }
     // ---- o projection + residual, post-attention norm
     if (decode) {
@@ -296,8 +311,10 @@ extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int
     HIPCHK(hipMemcpyAsync(m->w_ids.p, ids, (size_t)T * 4, hipMemcpyHostToDevice, s));
     for (int c = 0; c < 3; ++c)
         HIPCHK(hipMemcpyAsync(m->w_pos.as<int>() + (size_t)c * m->Tcap, pos3 + (size_t)c * T, (size_t)T * 4, hipMemcpyHostToDevice, s));
-    const int cu_q[2] = {0, T};
-    HIPCHK(hipMemcpyAsync(m->w_cu.p, cu_q, 8, hipMemcpyHostToDevice, s));
+    int cu_host[2 * GEN_ATT_SPLITS + 2] = {0};
+    cu_host[1] = T;                                   // cu_q = {0, T}
+    cu_host[GEN_ATT_SPLITS + 2] = T;                  // cu_kv = {0, T}
+    HIPCHK(hipMemcpyAsync(m->w_cu.p, cu_host, sizeof(cu_host), hipMemcpyHostToDevice, s));
     HIPCHK(launch_mark_seen(m->w_ids.as<int>(), T, m->w_seen.as<unsigned>(), m->V, s));
     HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
     if (n_embed > 0) {
@@ -323,11 +340,19 @@ extern "C" int vg_decode(vg_model_t m, int32_t token, const int32_t pos[3], void
     hipStream_t s = (hipStream_t)stream;
     const int E = m->E;
     // one token: id, its three positions and cu_q = {0, 1} travel as one small pinned-free copy each (a few bytes)
-    const int one[2] = {0, 1};
+    // KV ranges of this step's attention: multiples of the kernel's 64-key tile, enough of them for ~8 workgroups per head
+    const int L = m->len + 1;
+    int splits = std::min(GEN_ATT_SPLITS, std::max(1, (L + 127) / 128));
+    const int chunk = ((L + splits - 1) / splits + 63) / 64 * 64;
+    splits = (L + chunk - 1) / chunk;
+    m->dec_splits = splits;
+    int cu_host[2 * GEN_ATT_SPLITS + 2] = {0};
+    for (int i = 0; i <= splits; ++i) { cu_host[i] = splits > 1 ? i : std::min(i, 1); cu_host[GEN_ATT_SPLITS + 1 + i] = std::min(L, i * chunk); }
+    if (splits == 1) { cu_host[1] = 1; cu_host[GEN_ATT_SPLITS + 2] = L; }
     HIPCHK(hipMemcpyAsync(m->w_ids.p, &token, 4, hipMemcpyHostToDevice, s));
     for (int c = 0; c < 3; ++c)
         HIPCHK(hipMemcpyAsync(m->w_pos.as<int>() + (size_t)c * m->Tcap, pos + c, 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(m->w_cu.p, one, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->w_cu.p, cu_host, sizeof(cu_host), hipMemcpyHostToDevice, s));
     HIPCHK(launch_embed_gather(m->w_ids.as<int>(), 1, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
     HIPCHK(launch_rmsnorm(m->w_h.as<float>(), 1, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
     const int nl = (int)m->layers.size();

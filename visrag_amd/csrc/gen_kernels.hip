@@ -149,4 +149,23 @@ hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int 
     return hipGetLastError();
 }
 
+// one decode step's attention was run as S independent KV ranges (attention_kernel with q_shared): merge them
+__global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, const float* __restrict__ lse, int S, int heads,
+                                    bf16_t* __restrict__ out) {
+    const int h = blockIdx.x, d = threadIdx.x;        // 128 threads: one per channel of the head
+    float mx = -INFINITY;
+    for (int s = 0; s < S; ++s) mx = fmaxf(mx, lse[s * heads + h]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float w = exp2f(lse[s * heads + h] - mx);
+        num += w * bf2f(part[(size_t)s * ldp + h * 128 + d]);
+        den += w;
+    }
+    out[h * 128 + d] = f2bf(num / den);
+}
+hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s) {
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(heads), dim3(128), 0, s, (const bf16_t*)part, ldp, lse, S, heads, (bf16_t*)out);
+    return hipGetLastError();
+}
+
 }  // namespace vr

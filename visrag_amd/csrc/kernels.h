@@ -70,6 +70,8 @@ struct AttnArgs {
     int causal, q_shared;            // q_shared: q rows [0,max_q) are the same for every batch item
     float scale;
     int kv_group;                    // grouped-query attention: query head h reads K/V head h / kv_group (0 or 1: one each)
+    float* lse;                      // optional f32 [rows_q][heads]: log2 of the row's softmax denominator (with the running
+                                     // max folded in) — lets a caller merge attention over separately processed KV ranges
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -86,6 +88,9 @@ hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hi
 hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
                          unsigned long long seed, unsigned step, int* token_out, hipStream_t s);
 hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int dim, float* dst, int ld, hipStream_t s);
+// out[h*128 + d] = sum_s 2^(lse[s][h] - max) * part[s][h*128 + d] / sum_s 2^(lse[s][h] - max): merges the S partial
+// attention rows (bf16 [S][ldp], each normalised over its own KV range) of one decode step
+hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s);
 
 // ---- elementwise / gather / pooling (misc.hip) ---------------------------------------------
 // Fused ToTensor/Normalize + patch-embed conv (patch_embed.hip): g carries the PERMUTED weight (k = ky*3P + kx*3 + c),
