@@ -333,6 +333,12 @@ def main():
                 e_.close()
         except Exception as e:   # informational
             result["extras_error"] = repr(e)
+        # BASELINE config 5, language-model part: EVisRAG-7B-shaped generation over the top-5 pages
+        try:
+            from visrag_amd.evisrag import bench_generate
+            result["evisrag_generate"] = bench_generate(5, 64, 2, local_rank)
+        except Exception as e:   # informational
+            result["evisrag_error"] = repr(e)
 
     # ---- CPU baseline: the oracle (fp32 restatement of the reference) on the host cores, rank 0, N=1.
     #      kind "port": /root/reference does not exist on the GPU box, so the timed code is oracle/ (pinned to

@@ -46,35 +46,18 @@ def tiny_config() -> QwenGenConfig:
                          intermediate_size=512, vocab_size=1024, max_position_embeddings=512)
 
 
-def weight_specs(cfg: QwenGenConfig):
-    """HF state-dict keys of the language model (Qwen2_5_VLForConditionalGeneration) -> (shape, amplitude, offset)."""
-    H, KV, hd, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size
-    E = cfg.hidden_size
-    lin = lambda fan_in, g=1.0: g * math.sqrt(3.0 / fan_in)
-    specs = {"model.language_model.embed_tokens.weight": ((cfg.vocab_size, E), 0.05, 0.0)}
-    for l in range(cfg.num_hidden_layers):
-        p = f"model.language_model.layers.{l}."
-        specs[p + "self_attn.q_proj.weight"] = ((H * hd, E), lin(E), 0.0)
-        specs[p + "self_attn.q_proj.bias"] = ((H * hd,), 0.1, 0.0)
-        specs[p + "self_attn.k_proj.weight"] = ((KV * hd, E), lin(E), 0.0)
-        specs[p + "self_attn.k_proj.bias"] = ((KV * hd,), 0.1, 0.0)
-        specs[p + "self_attn.v_proj.weight"] = ((KV * hd, E), lin(E), 0.0)
-        specs[p + "self_attn.v_proj.bias"] = ((KV * hd,), 0.1, 0.0)
-        specs[p + "self_attn.o_proj.weight"] = ((E, H * hd), lin(H * hd, 0.5), 0.0)
-        specs[p + "mlp.gate_proj.weight"] = ((I, E), lin(E), 0.0)
-        specs[p + "mlp.up_proj.weight"] = ((I, E), lin(E), 0.0)
-        specs[p + "mlp.down_proj.weight"] = ((E, I), lin(I, 0.5), 0.0)
-        specs[p + "input_layernorm.weight"] = ((E,), 0.1, 1.0)
-        specs[p + "post_attention_layernorm.weight"] = ((E,), 0.1, 1.0)
-    specs["model.language_model.norm.weight"] = ((E,), 0.1, 1.0)
-    specs["lm_head.weight"] = ((cfg.vocab_size, E), lin(E, 2.0), 0.0)
-    return specs
+def _gen_config(cfg: QwenGenConfig):
+    from visrag_amd.evisrag import GenConfig
+    return GenConfig(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_key_value_heads, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
+                     rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, mrope_section=tuple(cfg.mrope_section))
 
 
 def synth_weights(cfg: QwenGenConfig, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
-    """Deterministic bf16-representable weights (visrag_amd.synth's counter hash), identical on CPU and GPU."""
-    from visrag_amd.synth import synth_tensor
-    return {k: synth_tensor(k, shape, amp, seed, off, device=device) for k, (shape, amp, off) in weight_specs(cfg).items()}
+    """The deterministic bf16-representable synthetic weights the product's tests and benchmarks load
+    (visrag_amd.evisrag.gen_weight_specs / visrag_amd.synth's counter hash), identical on CPU and GPU."""
+    from visrag_amd.evisrag import iter_synth_gen_weights
+    return dict(iter_synth_gen_weights(_gen_config(cfg), seed, device=device))
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:   # modeling_qwen2_5_vl.py:65-83

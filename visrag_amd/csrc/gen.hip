@@ -109,7 +109,7 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
         {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(std::max<size_t>(m->QKV, E), (size_t)pad128(2 * m->I)) * 4}, {&m->w_logits, (size_t)m->V * 4},
         {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, (2 * GEN_ATT_SPLITS + 2) * 4},
         {&m->w_attp, (size_t)GEN_ATT_SPLITS * m->QD * 2}, {&m->w_lse, (size_t)GEN_ATT_SPLITS * m->H * 4}, {&m->w_seen, (size_t)(m->V + 31) / 32 * 4},
-        {&m->w_tok, 16}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4}};
+        {&m->w_tok, 16 + 64 * 8}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4}};
     for (auto& w : ws)
         if ((rc = w.b->alloc(w.bytes)) != VR_OK) return bail(rc);
     return VR_OK;
@@ -370,7 +370,7 @@ extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penal
     VRCHK(set_dev(m->device));
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(launch_sample(m->w_logits.as<float>(), m->V, m->w_seen.as<unsigned>(), repetition_penalty, temperature, seed,
-                         (unsigned)step, m->w_tok.as<int>(), s));
+                         (unsigned)step, m->w_tok.as<int>(), m->w_tok.as<unsigned long long>() + 2, s));
     HIPCHK(hipMemcpyAsync(token_out, m->w_tok.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return VR_OK;

@@ -97,23 +97,32 @@ hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hi
 
 // Next token from one row of logits: repetition penalty on the seen ids (logit > 0 ? / penalty : * penalty — vLLM's
 // and HF's RepetitionPenaltyLogitsProcessor), then argmax of logit / temperature + Gumbel noise (an exact sample of
-// softmax(logit / temperature); temperature 0 = plain argmax, ties to the lowest id like torch.argmax).  One
-// workgroup; writes the token, marks it seen.
-__global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ logits, int vocab, unsigned* __restrict__ seen,
-                                                      float penalty, float temperature, unsigned long long seed,
-                                                      unsigned step, int* __restrict__ token_out) {
-    __shared__ unsigned long long best[16];
+// softmax(logit / temperature); temperature 0 = plain argmax, ties to the lowest id like torch.argmax).
+// Two launches: SAMPLE_WGS workgroups reduce their slice of the vocabulary to one (score, id) key each, one wave picks
+// the best of them, writes the token and marks it seen (a single workgroup over 152k logits took 94 us).
+constexpr int SAMPLE_WGS = 64;
+
+__device__ __forceinline__ unsigned long long sample_key(float l, bool seen, float penalty, float inv_t, bool noisy,
+                                                         unsigned long long seed, unsigned step, unsigned i) {
+    if (seen) l = l > 0.f ? l / penalty : l * penalty;
+    float sc = l * inv_t;
+    if (noisy) sc += gumbel_noise(seed, step, i);
+    unsigned b = __float_as_uint(sc);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                     // order-preserving map of the float
+    return ((unsigned long long)b << 32) | (unsigned)(~i);              // ties: the lowest id wins
+}
+
+__global__ __launch_bounds__(256) void sample_partial_kernel(const float* __restrict__ logits, int vocab,
+                                                             const unsigned* __restrict__ seen, float penalty, float temperature,
+                                                             unsigned long long seed, unsigned step,
+                                                             unsigned long long* __restrict__ part) {
+    __shared__ unsigned long long best[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float inv_t = temperature > 0.f ? 1.0f / temperature : 1.0f;
     unsigned long long key = 0ull;
-    for (int i = tid; i < vocab; i += 1024) {
-        float l = logits[i];
-        if ((seen[i >> 5] >> (i & 31)) & 1u) l = l > 0.f ? l / penalty : l * penalty;
-        float sc = l * inv_t;
-        if (temperature > 0.f) sc += gumbel_noise(seed, step, (unsigned)i);
-        unsigned b = __float_as_uint(sc);
-        b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                 // order-preserving map of the float
-        const unsigned long long k = ((unsigned long long)b << 32) | (unsigned)(~(unsigned)i);   // ties: lowest id wins
+    for (int i = blockIdx.x * 256 + tid; i < vocab; i += SAMPLE_WGS * 256) {
+        const unsigned long long k = sample_key(logits[i], (seen[i >> 5] >> (i & 31)) & 1u, penalty, inv_t, temperature > 0.f, seed,
+                                                step, (unsigned)i);
         key = k > key ? k : key;
     }
 #pragma unroll
@@ -125,15 +134,33 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
     __syncthreads();
     if (tid == 0) {
         unsigned long long k = best[0];
-        for (int w = 1; w < 16; ++w) k = best[w] > k ? best[w] : k;
-        const int tok = (int)(~(unsigned)(k & 0xFFFFFFFFull));
+        for (int w = 1; w < 4; ++w) k = best[w] > k ? best[w] : k;
+        part[blockIdx.x] = k;
+    }
+}
+
+__global__ __launch_bounds__(64) void sample_final_kernel(const unsigned long long* __restrict__ part, unsigned* __restrict__ seen,
+                                                          int* __restrict__ token_out) {
+    unsigned long long key = part[threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off, 64);
+        key = o > key ? o : key;
+    }
+    if (threadIdx.x == 0) {
+        const int tok = (int)(~(unsigned)(key & 0xFFFFFFFFull));
         *token_out = tok;
         seen[tok >> 5] |= 1u << (tok & 31);
     }
 }
+
+// `scratch`: SAMPLE_WGS 64-bit words on the device
 hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
-                         unsigned long long seed, unsigned step, int* token_out, hipStream_t s) {
-    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), 0, s, logits, vocab, seen, penalty, temperature, seed, step, token_out);
+                         unsigned long long seed, unsigned step, int* token_out, unsigned long long* scratch, hipStream_t s) {
+    static_assert(SAMPLE_WGS == 64, "the final reduction is one wave");
+    hipLaunchKernelGGL(sample_partial_kernel, dim3(SAMPLE_WGS), dim3(256), 0, s, logits, vocab, (const unsigned*)seen, penalty,
+                       temperature, seed, step, scratch);
+    hipLaunchKernelGGL(sample_final_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)scratch, seen, token_out);
     return hipGetLastError();
 }
 

@@ -86,7 +86,7 @@ hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_pa
 hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hipStream_t s);
 // repetition penalty over the seen ids, temperature sampling (Gumbel-max; 0 = argmax), marks the chosen token seen
 hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
-                         unsigned long long seed, unsigned step, int* token_out, hipStream_t s);
+                         unsigned long long seed, unsigned step, int* token_out, unsigned long long* scratch64, hipStream_t s);
 hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int dim, float* dst, int ld, hipStream_t s);
 // out[h*128 + d] = sum_s 2^(lse[s][h] - max) * part[s][h*128 + d] / sum_s 2^(lse[s][h] - max): merges the S partial
 // attention rows (bf16 [S][ldp], each normalised over its own KV range) of one decode step

@@ -63,6 +63,96 @@ class RequestOutput:        # pred.outputs[0].text (predict.py:154)
     prompt_token_ids: List[int] = field(default_factory=list)
 
 
+def gen_weight_specs(cfg: "GenConfig"):
+    """HF state-dict keys of the language model (Qwen2_5_VLForConditionalGeneration) -> (shape, amplitude, offset) of
+    the deterministic synthetic weights (visrag_amd.synth's counter hash) the tests and benchmarks load: there is no
+    checkpoint on the box."""
+    import math
+    H, KV, I, E = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size, cfg.hidden_size
+    hd = E // H
+    lin = lambda fan_in, g=1.0: g * math.sqrt(3.0 / fan_in)
+    specs = {"model.language_model.embed_tokens.weight": ((cfg.vocab_size, E), 0.05, 0.0)}
+    for l in range(cfg.num_hidden_layers):
+        p = f"model.language_model.layers.{l}."
+        specs[p + "self_attn.q_proj.weight"] = ((H * hd, E), lin(E), 0.0)
+        specs[p + "self_attn.q_proj.bias"] = ((H * hd,), 0.1, 0.0)
+        specs[p + "self_attn.k_proj.weight"] = ((KV * hd, E), lin(E), 0.0)
+        specs[p + "self_attn.k_proj.bias"] = ((KV * hd,), 0.1, 0.0)
+        specs[p + "self_attn.v_proj.weight"] = ((KV * hd, E), lin(E), 0.0)
+        specs[p + "self_attn.v_proj.bias"] = ((KV * hd,), 0.1, 0.0)
+        specs[p + "self_attn.o_proj.weight"] = ((E, H * hd), lin(H * hd, 0.5), 0.0)
+        specs[p + "mlp.gate_proj.weight"] = ((I, E), lin(E), 0.0)
+        specs[p + "mlp.up_proj.weight"] = ((I, E), lin(E), 0.0)
+        specs[p + "mlp.down_proj.weight"] = ((E, I), lin(I, 0.5), 0.0)
+        specs[p + "input_layernorm.weight"] = ((E,), 0.1, 1.0)
+        specs[p + "post_attention_layernorm.weight"] = ((E,), 0.1, 1.0)
+    specs["model.language_model.norm.weight"] = ((E,), 0.1, 1.0)
+    specs["lm_head.weight"] = ((cfg.vocab_size, E), lin(E, 2.0), 0.0)
+    return specs
+
+
+def iter_synth_gen_weights(cfg: "GenConfig", seed: int = 0, device="cpu", bf16: bool = False):
+    from .synth import synth_tensor
+    import torch
+    for k, (shape, amp, off) in gen_weight_specs(cfg).items():
+        t = synth_tensor(k, shape, amp, seed, off, device=device)
+        yield k, (t.to(torch.bfloat16) if bf16 else t)
+
+
+def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2, device: int = 0) -> dict:
+    """EVisRAG-7B-shaped generation (BASELINE config 5: the top retrieved pages go to the generator, one query at a
+    time like src/evisrag/predict.py:128-149): random weights of the Qwen2.5-VL-7B language model, image tokens as
+    precomputed embedding rows (16 x 16 merged tokens per 448 x 448 page).  Returns prefill / decode timings, the
+    queries/s for this answer length and the decode step's weight-streaming rate against the HBM."""
+    import time
+    import torch
+    cfg = GenConfig()
+    t0 = time.time()
+    llm = LLM(cfg, limit_mm_per_prompt={"image": max(5, n_images)}, max_model_len=4096, max_prefill=2048, device=device)
+    llm.load_weights(iter_synth_gen_weights(cfg, 0, device=f"cuda:{device}", bf16=True))
+    torch.cuda.synchronize(device)
+    t_load = time.time() - t0
+    specs = gen_weight_specs(cfg)
+    params = sum(int(np.prod(s)) for s, _, _ in specs.values())
+    stream = params - cfg.vocab_size * cfg.hidden_size           # the embedding table is gathered, not streamed
+    rng = np.random.default_rng(0)
+    grid = (16, 16)
+    ids = [int(t) for t in rng.integers(1000, 50000, 60)]
+    for _ in range(n_images):
+        ids += [cfg.image_token_id] * (grid[0] * grid[1]) + [198]
+    ids += [int(t) for t in rng.integers(1000, 50000, 60)]
+    embs = [(rng.standard_normal((grid[0] * grid[1], cfg.hidden_size)) * 0.05).astype(np.float32) for _ in range(n_images)]
+    sp = SamplingParams(temperature=0.1, repetition_penalty=1.05, max_tokens=answer_tokens, stop_token_ids=())
+    llm.generate([{"prompt_token_ids": ids, "multi_modal_data": {"image_embeds": embs, "image_grids": [grid] * n_images}}],
+                 SamplingParams(temperature=0.1, repetition_penalty=1.05, max_tokens=4, stop_token_ids=()))      # warm-up
+    pre, dec, tot = [], [], []
+    for _ in range(queries):
+        torch.cuda.synchronize(device); a = time.perf_counter()
+        pos3 = llm.prefill(ids, embs, [grid] * n_images)
+        tok = llm.sample(sp, 0)
+        torch.cuda.synchronize(device); b = time.perf_counter()
+        nxt = int(pos3.max()) + 1
+        for step in range(1, answer_tokens):
+            llm.decode(tok, nxt); nxt += 1
+            tok = llm.sample(sp, step)
+        torch.cuda.synchronize(device); c = time.perf_counter()
+        pre.append(b - a); dec.append((c - b) / max(1, answer_tokens - 1)); tot.append(c - a)
+    llm.close()
+    T, p_s, d_s = len(ids), float(np.median(pre)), float(np.median(dec))
+    return {
+        "workload": f"Qwen2.5-VL-7B-shaped language model, bf16, random weights; prompt {T} tokens ({n_images} pages x 256 image tokens "
+                    f"as embedding rows + text), {answer_tokens} answer tokens, temperature 0.1, repetition_penalty 1.05, one query "
+                    "at a time; vision tower not included",
+        "params_billion": round(params / 1e9, 3), "load_s": round(t_load, 1),
+        "prefill_ms": round(p_s * 1e3, 2), "prefill_tokens_per_s": round(T / p_s), "prefill_tflops": round(2.0 * stream * T / p_s / 1e12, 1),
+        "decode_ms_per_token": round(d_s * 1e3, 3), "decode_tokens_per_s": round(1.0 / d_s, 1),
+        "queries_per_s": round(1.0 / float(np.median(tot)), 3),
+        "queries_per_s_at_2048_tokens": round(1.0 / (p_s + 2047 * d_s), 4),
+        "roofline": {"bound": "hbm", "kernel": "decode step: vr::gemm_skinny_kernel (M = 1 weight streaming) + attention + norms",
+                     "achieved": round(stream * 2 / d_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(stream * 2 / d_s / 8e12, 4),
+                     "bytes_per_token": stream * 2}}
+
+
 def rope_index(ids: Sequence[int], image_token_id: int, grids: Sequence[Tuple[int, int]]) -> np.ndarray:
     """[3][T] temporal / height / width positions of a prompt whose images are runs of `image_token_id`, one run of
     h*w placeholders per (h, w) in `grids`, in order (Qwen2.5-VL get_rope_index for still images)."""
