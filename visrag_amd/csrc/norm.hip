@@ -8,9 +8,10 @@
 
 namespace vr {
 
-constexpr int NORM_MAXV = 14;   // float4 per lane: rows up to 64*4*14 = 3584 columns (the generator's hidden size)
+constexpr int NORM_MAXV = 14;   // float4 per lane at most: rows up to 64*4*14 = 3584 columns (the generator's hidden size)
+constexpr int NORM_STDV = 10;   // the encoder's rows (<= 2560 columns) keep the 10-register form: 14 costs its LayerNorm 14 %
 
-template <bool RMS>
+template <bool RMS, int MAXV = NORM_STDV>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int rows, int dim, int ldx,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ b, float eps,
@@ -20,10 +21,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     if (row >= rows) return;
     const int nv = dim >> 2;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * ldx);
-    f32x4 v[NORM_MAXV];
+    f32x4 v[MAXV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NORM_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         v[i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (RMS) s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
         mu = s / dim;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NORM_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
 #pragma unroll
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     }
     bf16_t* orow = out + (size_t)row * ldo;
 #pragma unroll
-    for (int i = 0; i < NORM_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const f32x4 ww = reinterpret_cast<const f32x4*>(w)[c];
@@ -69,8 +70,10 @@ hipError_t launch_layernorm(const float* x, int rows, int dim, int ldx, const fl
                             float eps, void* out, int ldo, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (dim % 4 || ldo % 4 || ldx % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo || dim > ldx) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, b, eps,
-                       (bf16_t*)out, ldo);
+    if (ldo <= 64 * 4 * NORM_STDV)
+        hipLaunchKernelGGL((norm_kernel<false, NORM_STDV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, b, eps, (bf16_t*)out, ldo);
+    else
+        hipLaunchKernelGGL((norm_kernel<false, NORM_MAXV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, b, eps, (bf16_t*)out, ldo);
     return hipGetLastError();
 }
 
@@ -78,14 +81,17 @@ hipError_t launch_rmsnorm(const float* x, int rows, int dim, int ldx, const floa
                           int ldo, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (dim % 4 || ldo % 4 || ldx % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo || dim > ldx) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w,
-                       (const float*)nullptr, eps, (bf16_t*)out, ldo);
+    if (ldo <= 64 * 4 * NORM_STDV)
+        hipLaunchKernelGGL((norm_kernel<true, NORM_STDV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, (const float*)nullptr, eps, (bf16_t*)out, ldo);
+    else
+        hipLaunchKernelGGL((norm_kernel<true, NORM_MAXV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, (const float*)nullptr, eps, (bf16_t*)out, ldo);
     return hipGetLastError();
 }
 
 // Residual update fused into the RMSNorm that follows it: x <- x + alpha * (partial[0] + partial[1]
 // + ...), the split-K partial products of the o / down projections (fp32, summed in a fixed
 // order), then the usual RMSNorm of the new x.  One wave per row, the row stays in registers.
+template <int MAXV>
 __global__ __launch_bounds__(256) void rmsnorm_accum_kernel(float* __restrict__ x, int rows, int dim, int ldx,
                                                             const float* __restrict__ partial, int nsplit,
                                                             size_t split_stride, int ldp, float alpha,
@@ -96,10 +102,10 @@ __global__ __launch_bounds__(256) void rmsnorm_accum_kernel(float* __restrict__ 
     if (row >= rows) return;
     const int nv = dim >> 2;
     f32x4* xr = reinterpret_cast<f32x4*>(x + (size_t)row * ldx);
-    f32x4 v[NORM_MAXV];
+    f32x4 v[MAXV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NORM_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             f32x4 acc = reinterpret_cast<const f32x4*>(partial + (size_t)row * ldp)[c];
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256) void rmsnorm_accum_kernel(float* __restrict__ 
     const float rstd = rsqrtf(s / dim + eps);
     bf16_t* orow = out + (size_t)row * ldo;
 #pragma unroll
-    for (int i = 0; i < NORM_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const f32x4 y = v[i] * rstd * reinterpret_cast<const f32x4*>(w)[c];
@@ -181,8 +187,12 @@ hipError_t launch_rmsnorm_accum(float* x, int rows, int dim, int ldx, const floa
                            alpha, w, eps, (bf16_t*)out, ldo);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(rmsnorm_accum_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, partial, nsplit,
-                       split_stride, ldp, alpha, w, eps, (bf16_t*)out, ldo);
+    if (dim <= 64 * 4 * NORM_STDV && (!out || ldo <= 64 * 4 * NORM_STDV))
+        hipLaunchKernelGGL(rmsnorm_accum_kernel<NORM_STDV>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, partial, nsplit,
+                           split_stride, ldp, alpha, w, eps, (bf16_t*)out, ldo);
+    else
+        hipLaunchKernelGGL(rmsnorm_accum_kernel<NORM_MAXV>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, partial, nsplit,
+                           split_stride, ldp, alpha, w, eps, (bf16_t*)out, ldo);
     return hipGetLastError();
 }
 
