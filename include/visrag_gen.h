@@ -6,13 +6,14 @@
  *   src/evisrag/predict.py:119-123   SamplingParams(temperature=..., repetition_penalty=1.05, max_tokens=2048)
  *   src/evisrag/predict.py:147       llm.generate(batch_input, sampling_params)      (one prompt at a time, :128)
  * vLLM is not vendored (vllm==0.9.1, EVisRAG_requirements.txt:236); the model is Qwen2.5-VL (EVisRAG-7B).  This ABI
- * covers the decoder: prefill over the prompt's token embeddings (image tokens arrive as embedding rows — the vision
- * tower is not part of this library yet), KV cache, one-token decode steps, and vLLM's logits processing
- * (repetition penalty over prompt + output, temperature; 0 = greedy).  visrag_amd/evisrag.py mirrors the
- * LLM / SamplingParams / generate call sites on top of it.
+ * covers the decoder — prefill over the prompt's token embeddings, KV cache, one-token decode steps, vLLM's logits
+ * processing (repetition penalty over prompt + output, temperature; 0 = greedy) — and the vision tower that turns the
+ * page images of predict.py:98-103,140 into the embedding rows of the prompt's image tokens (vg_vision_*).
+ * visrag_amd/evisrag.py mirrors the LLM / SamplingParams / generate call sites on top of it.
  *
  * Same conventions as visrag_hip.h: plain pointers and sizes, 0 = OK, vr_last_error() for the message.
- * State-dict keys of Qwen2_5_VLForConditionalGeneration's language model are consumed verbatim by vg_load_weight. */
+ * State-dict keys of Qwen2_5_VLForConditionalGeneration ("model.language_model.*", "lm_head.weight", and with a tower
+ * attached "model.visual.*") are consumed verbatim by vg_load_weight. */
 #ifndef VISRAG_GEN_H
 #define VISRAG_GEN_H
 #include <stdint.h>
@@ -39,6 +40,41 @@ typedef struct {
 
 int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out);
 int vg_destroy(vg_model_t m);
+/* The vision tower (Qwen2_5_VisionTransformerPretrainedModel; HF modeling_qwen2_5_vl.py:345-470). */
+typedef struct {
+    int32_t depth;                  /* 32 */
+    int32_t hidden_size;            /* 1280 */
+    int32_t num_heads;              /* 16: head_dim 80 (a multiple of 4, at most 128) */
+    int32_t intermediate_size;      /* 3420 */
+    int32_t out_hidden_size;        /* 3584 = the language model's hidden_size */
+    int32_t in_channels;            /* 3 */
+    int32_t patch_size;             /* 14 */
+    int32_t temporal_patch_size;    /* 2 */
+    int32_t spatial_merge_size;     /* 2: 2 x 2 patches become one image token */
+    int32_t window_size;            /* 112 pixels */
+    int32_t n_fullatt;              /* 4 */
+    int32_t fullatt_blocks[16];     /* 7, 15, 23, 31: the blocks that attend over whole images */
+    int32_t max_rows;               /* most patch rows (sum of t*h*w over the images) of one vg_vision_encode call */
+    float rms_norm_eps;             /* 1e-6 */
+} vg_vision_config_t;
+
+/* Attach a tower to a model (before its weights are loaded; without one, "model.visual.*" tensors are skipped). */
+int vg_vision_create(vg_model_t m, const vg_vision_config_t* cfg);
+/* Run the tower.
+ *   pixels     host f32 [rows][in_channels * temporal_patch_size * patch_size^2]: the image processor's pixel_values
+ *              (rows in its merge-block-major order, all images concatenated; converted to bf16 on the device like the
+ *              reference's bf16 model does)
+ *   grid_thw   host int32 [n_images][3]: frames, patch rows, patch columns of every image (image_grid_thw)
+ *   embeds_out host f32 [rows / merge^2][out_hidden_size] or NULL: the image tokens' embeddings, image by image
+ * The embeddings also stay on the device: a vg_prefill with embeds == NULL and n_embed == rows / merge^2 uses them. */
+int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t* grid_thw, int32_t n_images, float* embeds_out,
+                     void* stream);
+/* Host-only (no GPU needed): the tower's token geometry for a set of grids — tests.  order [tokens]: the image token at
+ * window-order place i; win_bounds [n_windows + 1]: patch-row boundaries of the attention windows in that order;
+ * hw [rows][2]: patch coordinates of every pixel row.  Any output may be NULL. */
+int vg_vision_plan(const vg_vision_config_t* cfg, const int32_t* grid_thw, int32_t n_images, int32_t* order,
+                   int32_t* win_bounds, int32_t* n_windows, int32_t* hw);
+
 /* one tensor of the HF state dict ("model.language_model.layers.0.self_attn.q_proj.weight", "lm_head.weight", ...);
  * dtype / on_device as in vr_model_load_weight (0 = f32, 1 = bf16; data on the host or on this device) */
 int vg_load_weight(vg_model_t m, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t dtype,
@@ -49,7 +85,8 @@ int vg_finalize(vg_model_t m);      /* checks that every tensor arrived */
  *   ids          [T] host int32: token ids (their embedding rows are gathered; all of them count as "seen" for the
  *                repetition penalty, placeholders included — like the prompt_token_ids vLLM penalises)
  *   embed_rows   [n_embed] host int32 (or NULL): prompt positions whose embedding is replaced ...
- *   embeds       ... by row i of this host f32 [n_embed][hidden] matrix (the image tokens)
+ *   embeds       ... by row i of this host f32 [n_embed][hidden] matrix (the image tokens); NULL = the rows the last
+ *                vg_vision_encode left on the device (n_embed must equal their number)
  *   pos3         [3][T] host int32: temporal / height / width position of every token (get_rope_index)
  * Leaves the last token's logits on the device for vg_sample. */
 int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int32_t* embed_rows, const float* embeds, int32_t n_embed,

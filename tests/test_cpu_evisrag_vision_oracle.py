@@ -99,3 +99,100 @@ def test_prompt_with_images_matches_hf_logits_and_positions():
     lm.reset()
     logits = lm.forward(emb, torch.from_numpy(pos).long())[-1]
     np.testing.assert_allclose(logits.numpy(), g["prompt_logits"], rtol=2e-4, atol=3e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the product's host side (visrag_amd/evisrag.py + the host-only entry point of the library) against the oracle
+# ---------------------------------------------------------------------------------------------------------------
+
+def _product_vc(cfg):
+    from visrag_amd.evisrag import VisionConfig
+    return VisionConfig(depth=cfg.depth, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads, intermediate_size=cfg.intermediate_size,
+                        out_hidden_size=cfg.out_hidden_size, window_size=cfg.window_size,
+                        fullatt_block_indexes=tuple(cfg.fullatt_block_indexes))
+
+
+@pytest.mark.parametrize("grids", [[(1, 10, 6), (1, 4, 8), (1, 2, 2)], [(2, 6, 10)], [(1, 32, 32), (1, 18, 46)], [(1, 2, 2)]])
+@pytest.mark.parametrize("full_size", [False, True])
+def test_library_token_geometry_matches_the_oracle(grids, full_size):
+    """vg_vision_plan (host-only C++ in gen_vision.hip) == the oracle's window order / boundaries / coordinates."""
+    from oracle.qwen_vision_oracle import QwenVisionConfig
+    from visrag_amd.evisrag import vision_plan
+    cfg = QwenVisionConfig() if full_size else tiny_vision_config()        # windows of 4 x 4 or 2 x 2 merged tokens
+    order, bounds, hw = vision_plan(_product_vc(cfg), grids)
+    o_order, o_bounds = window_order(grids, cfg)
+    assert order.tolist() == o_order.tolist()
+    assert bounds.tolist() == o_bounds
+    np.testing.assert_array_equal(hw, position_hw(grids, cfg.spatial_merge_size).numpy())
+
+
+def test_process_images_matches_the_hf_processor():
+    from PIL import Image
+    from visrag_amd.evisrag import VisionConfig, process_images, smart_resize as product_smart_resize
+    g = np.load(GOLD)
+    mn, mx = (int(v) for v in g["proc_min_max_pixels"])
+    vc = VisionConfig(min_pixels=mn, max_pixels=mx)
+    px, grid = process_images([Image.fromarray(g["proc_rgb"])], vc)
+    np.testing.assert_array_equal(grid, g["proc_grid"])
+    np.testing.assert_allclose(px, g["proc_pixel_values"], rtol=1e-5, atol=1e-5)
+    for hw in [(1000, 700), (3000, 2000), (20, 30), (1, 150), (4000, 100)]:
+        assert product_smart_resize(*hw, 28, 3136, 1003520) == smart_resize(*hw, 28, 3136, 1003520)
+    # two pages of different sizes: rows concatenate, one grid row per page
+    px2, grid2 = process_images([Image.fromarray(g["proc_rgb"]), Image.fromarray(g["proc_rgb"][:60, :90])], vc)
+    assert grid2.shape == (2, 3) and px2.shape[0] == int((grid2[:, 1] * grid2[:, 2]).sum())
+    np.testing.assert_array_equal(px2[:px.shape[0]], px)
+
+
+def test_head_slot_layout_reproduces_the_oracle():
+    """The layout gen_vision.hip gives the attention side — every head in a 128-wide slot, its two rotate-half halves at
+    slot channels [0, hd/2) and [64, 64 + hd/2), rotary over slot pairs (p, p + 64) with the table
+    f[p] = 10000^(-2 (p mod hd/4) / (hd/2)) and the position component h for p < hd/4, w beyond — is arithmetic-for-
+    arithmetic the tower's attention.  (fp32 torch emulation of the packing formulas; the kernels are -m gpu.)"""
+    g = np.load(GOLD)
+    cfg = tiny_vision_config()
+    w = _weights(g)
+    H, nh, hd = cfg.hidden_size, cfg.num_heads, cfg.head_dim
+    half, quarter = hd // 2, hd // 4
+    grids = _grids(g)
+    torch.manual_seed(0)
+    x = torch.randn(96, H)
+    order, wb = window_order(grids, cfg)
+    perm = (order[:, None] * 4 + torch.arange(4)[None]).reshape(-1)
+    hw = position_hw(grids, 2)[perm].float()
+    # reference: the oracle's attention of block 0 on window-ordered rows
+    o = QwenVisionOracle(cfg, w)
+    cos, sin = o.rotary(grids)
+    cos, sin = cos[perm], sin[perm]
+    b = "model.visual.blocks.0."
+    qkv = (x @ w[b + "attn.qkv.weight"].T + w[b + "attn.qkv.bias"]).reshape(96, 3, nh, hd)
+    rot = lambda t: torch.cat([-t[..., hd // 2:], t[..., :hd // 2]], -1)   # noqa: E731
+    q = qkv[:, 0] * cos[:, None] + rot(qkv[:, 0]) * sin[:, None]
+    k = qkv[:, 1] * cos[:, None] + rot(qkv[:, 1]) * sin[:, None]
+    ref = torch.empty(96, nh, hd)
+    for s, e in zip(wb[:-1], wb[1:]):
+        a = torch.softmax(torch.einsum("qhd,khd->hqk", q[s:e], k[s:e]) / hd ** 0.5, -1)
+        ref[s:e] = torch.einsum("hqk,khd->qhd", a, qkv[s:e, 2])
+    ref = ref.reshape(96, H) @ w[b + "attn.proj.weight"].T + w[b + "attn.proj.bias"]
+    # emulation of the packed form
+    rmap = lambda r: (r // half) * 64 + r % half                          # noqa: E731  (pack_weight_blocks: blk = half, stride 64)
+    Wp = torch.zeros(3 * nh * 128, H); bp = torch.zeros(3 * nh * 128)
+    idx = torch.tensor([rmap(r) for r in range(3 * H)])
+    Wp[idx] = w[b + "attn.qkv.weight"]; bp[idx] = w[b + "attn.qkv.bias"]
+    Pp = torch.zeros(H, nh * 128)
+    Pp[:, torch.tensor([rmap(c) for c in range(H)])] = w[b + "attn.proj.weight"]
+    table = torch.zeros(64)
+    for p in range(half):
+        table[p] = 1.0 / 10000.0 ** (2 * (p % quarter) / half)
+    sel = (torch.arange(64) >= quarter).long()                            # lane < hd/4 -> h, else w
+    ang = hw[:, sel] * table[None, :]                                     # [rows][64]
+    qkvp = (x @ Wp.T + bp).reshape(96, 3 * nh, 128)
+    x1, x2 = qkvp[..., :64], qkvp[..., 64:]
+    c_, s_ = ang.cos()[:, None], ang.sin()[:, None]
+    rotd = torch.cat([x1 * c_ - x2 * s_, x2 * c_ + x1 * s_], -1)
+    qp, kp, vp = rotd[:, :nh], rotd[:, nh:2 * nh], qkvp[:, 2 * nh:]
+    out = torch.empty(96, nh, 128)
+    for s, e in zip(wb[:-1], wb[1:]):
+        a = torch.softmax(torch.einsum("qhd,khd->hqk", qp[s:e], kp[s:e]) / hd ** 0.5, -1)
+        out[s:e] = torch.einsum("hqk,khd->qhd", a, vp[s:e])
+    got = out.reshape(96, nh * 128) @ Pp.T + w[b + "attn.proj.bias"]
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)

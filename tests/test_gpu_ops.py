@@ -88,6 +88,19 @@ def test_gemm_epilogues(variant):
 
 
 @pytest.mark.parametrize("variant", [0, 3, 9, 12])
+@pytest.mark.parametrize("M,I,K", [(200, 128, 128), (1500, 3456, 1280)])
+def test_gemm_swiglu_with_bias(variant, M, I, K):
+    """The vision tower's MLP: gate / up projections WITH bias, bias interleaved like the weight rows."""
+    A = _bf(_rand((M, K), 51))
+    Wg, Wu = _bf(_rand((I, K), 52, 0.05)), _bf(_rand((I, K), 53, 0.05))
+    bg, bu = _rand((I,), 54, 0.5), _rand((I,), 55, 0.5)
+    il = lambda g, u: torch.stack([g.reshape(I // 16, 16, *g.shape[1:]), u.reshape(I // 16, 16, *u.shape[1:])], dim=1).reshape(2 * I, *g.shape[1:])  # noqa: E731
+    ref = torch.nn.functional.silu(A.float() @ Wg.float().T + bg) * (A.float() @ Wu.float().T + bu)
+    out = op_gemm(A.to(DEV), il(Wg, Wu).to(DEV), 4, bias=il(bg, bu).to(DEV), out_cols=I, variant=variant).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("variant", [0, 3, 9, 12])
 def test_gemm_rope(variant):
     """EPI_ROPE == apply_rotary_pos_emb (modeling_minicpm.py:259-290) on q,k columns; v untouched."""
     M, E, K = 150, 256, 128            # 4 heads of 64; N = 3E
@@ -171,6 +184,26 @@ def test_attention(hd, heads, lens, causal):
                 got = out[lo:hi, h * hd:(h + 1) * hd]
             # P and the output are rounded to bf16: 2^-8 relative on O(1) values
             np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+
+
+def test_attention_segments_head_dim_128():
+    """The vision tower's form: head_dim-128 slots, bidirectional attention inside ragged row segments (windows of up
+    to 64 rows, whole images), own q rows per segment, a scale that is not 1/sqrt(128)."""
+    hd, heads = 128, 3
+    for lens in ([64, 32, 64, 16, 4, 240], [700, 64]):
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+        T, W = int(cu[-1]), heads * hd
+        qkv = _bf(_rand((T, 3 * W), 60, 1.0))
+        scale = 80 ** -0.5
+        d = qkv.to(DEV)
+        out = op_attention(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], cu.to(DEV), cu.to(DEV), heads, hd, max(lens), False, False,
+                           scale, T).float().cpu()
+        for b in range(len(lens)):
+            lo, hi = int(cu[b]), int(cu[b + 1])
+            for h in range(heads):
+                ref = _ref_attn(qkv[lo:hi, h * hd:(h + 1) * hd], qkv[lo:hi, W + h * hd:W + (h + 1) * hd],
+                                qkv[lo:hi, 2 * W + h * hd:2 * W + (h + 1) * hd], False, scale)
+                np.testing.assert_allclose(out[lo:hi, h * hd:(h + 1) * hd].numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
 def test_attention_spiked_scores():

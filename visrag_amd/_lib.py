@@ -36,6 +36,15 @@ class VGConfig(C.Structure):       # vg_config_t (include/visrag_gen.h)
     ]
 
 
+class VGVisionConfig(C.Structure):     # vg_vision_config_t (include/visrag_gen.h)
+    _fields_ = [
+        ("depth", C.c_int32), ("hidden_size", C.c_int32), ("num_heads", C.c_int32), ("intermediate_size", C.c_int32),
+        ("out_hidden_size", C.c_int32), ("in_channels", C.c_int32), ("patch_size", C.c_int32), ("temporal_patch_size", C.c_int32),
+        ("spatial_merge_size", C.c_int32), ("window_size", C.c_int32), ("n_fullatt", C.c_int32), ("fullatt_blocks", C.c_int32 * 16),
+        ("max_rows", C.c_int32), ("rms_norm_eps", C.c_float),
+    ]
+
+
 class VisragHipError(RuntimeError):
     pass
 
@@ -84,6 +93,9 @@ GEN_SIGNATURES = {
     "vg_decode": (C.c_int, [_vp, _i32, C.POINTER(_i32), _vp]),
     "vg_logits": (C.c_int, [_vp, _vp, _vp]),
     "vg_cache_len": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "vg_vision_create": (C.c_int, [_vp, C.POINTER(VGVisionConfig)]),
+    "vg_vision_encode": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "vg_vision_plan": (C.c_int, [C.POINTER(VGVisionConfig), _vp, _i32, _vp, _vp, C.POINTER(_i32), _vp]),
 }
 
 

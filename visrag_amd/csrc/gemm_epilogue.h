@@ -73,9 +73,14 @@ __device__ __forceinline__ void gemm_epilogue_row(f32x4 (&acc)[NF], const GemmAr
         for (int jj = 0; jj < 2; ++jj) {
             if (nb + jj * 32 >= p.N) continue;
             const int oc = nb / 2 + jj * 16 + fq * 4;
+            f32x4 g = acc[2 * jj], u = acc[2 * jj + 1];
+            if (p.bias) {                        // interleaved like the W rows: [16 gate | 16 up | ...]
+                g += *reinterpret_cast<const f32x4*>(p.bias + nb + jj * 32 + fq * 4);
+                u += *reinterpret_cast<const f32x4*>(p.bias + nb + jj * 32 + 16 + fq * 4);
+            }
             bf16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(acc[2 * jj][r]) * acc[2 * jj + 1][r]);
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(g[r]) * u[r]);
             *reinterpret_cast<bf16x4*>((bf16_t*)p.out + (size_t)orow * p.ldo + oc) = o;
         }
     } else if constexpr (EPI == EPI_ROPE) {
@@ -204,9 +209,14 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_general(f32x4 (&acc)[MI][
             // fragment j even = gate, j odd = up for the same 16 output columns (see gemm_epilogue_row)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
+                f32x4 g = acc[i][2 * jj], u = acc[i][2 * jj + 1];
+                if (p.bias && nb + jj * 32 < p.N) {
+                    g += *reinterpret_cast<const f32x4*>(p.bias + nb + jj * 32 + fq * 4);
+                    u += *reinterpret_cast<const f32x4*>(p.bias + nb + jj * 32 + 16 + fq * 4);
+                }
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r]);
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(g[r]) * u[r]);
                 const int c = jj * 2 + (fq >> 1);              // 16-byte chunk of the 64-byte output row
                 *reinterpret_cast<bf16x4*>(lrow + ((c ^ (row & 3)) << 4) + (fq & 1) * 8) = o;
             }
@@ -287,14 +297,22 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4]
     const lds_p wl = (lds_p)VR_LDS(wl_generic);
     const int fr = lane & 15, fq = lane >> 4;
     if constexpr (EPI == EPI_SWIGLU) {
+        f32x4 bias[4];                           // interleaved like the W rows: fragment j even = gate, odd = up
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias[j] = *reinterpret_cast<const f32x4*>(p.bias + min(nb + j * 16 + fq * 4, p.N - 4));
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int row = i * 16 + fr;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
+                const f32x4 g = acc[i][2 * jj] + bias[2 * jj], u = acc[i][2 * jj + 1] + bias[2 * jj + 1];
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(acc[i][2 * jj][r]) * acc[i][2 * jj + 1][r]);
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(g[r]) * u[r]);
                 const int c = jj * 2 + (fq >> 1);
                 *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4) + (fq & 1) * 8) = o;
             }

@@ -17,49 +17,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/visrag_gen.h"
-#include "engine_common.h"
-
-namespace {
-
-struct GenLayer {
-    Vec ln1, ln2;
-    Linear qkv, o, gu, down;
-    int parts_w = 0, parts_b = 0, parts_gu = 0;
-};
-
-constexpr int GEN_KS_MAX = 64;      // split-K planes of the decode path
-constexpr int GEN_ATT_SPLITS = 16;  // most KV ranges one decode step's attention is cut into
-
-}  // namespace
-
-struct vg_model_s {
-    int device = 0;
-    vg_config_t c{};
-    bool finalized = false;
-    int E = 0, H = 0, KV = 0, I = 0, V = 0, QKV = 0, QD = 0, KVD = 0;
-    DevBuf embed;
-    bool has_embed = false;
-    std::vector<GenLayer> layers;
-    Vec final_norm;
-    Linear lm_head;
-    DevBuf inv_freq;
-    std::vector<DevBuf> kc, vc;          // per layer [max_len][KVD] bf16
-    int len = 0;                         // rows of the cache in use
-    bool have_logits = false;
-    int Tcap = 0;
-    DevBuf w_h, w_xn, w_qkv, w_q, w_att, w_act, w_last, w_part, w_logits, w_ids, w_pos, w_cu, w_seen, w_tok, w_erows, w_emb;
-    DevBuf w_attp, w_lse;               // decode: partial attention rows [GEN_ATT_SPLITS][QD] bf16 + their log-sum-exps
-    int dec_splits = 1;                 // KV ranges of the current decode step (w_cu: cu_q at [0..], cu_kv at [GEN_ATT_SPLITS + 1..])
-};
-
-static GemmArgs gen_gemm_args(const void* A, int lda, const Linear& L, int M, void* out, int ldo) {
-    GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = L.w.p; a.ldw = L.k_pad; a.M = M; a.N = L.n_pad; a.K = L.k_pad;
-    a.bias = L.has_b ? L.b.as<float>() : nullptr;
-    a.out = out; a.ldo = ldo; a.alpha = 1.0f;
-    return a;
-}
+#include "gen_model.h"
 
 // decode (gemm_skinny.hip): split K so that (256-column tiles) x splits gives the chip about two workgroups per CU
 // to pull on; every split keeps >= 4 K-steps
@@ -118,6 +76,7 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
 extern "C" int vg_destroy(vg_model_t m) {
     if (!m) return VR_OK;
     (void)hipSetDevice(m->device);
+    vision_destroy(m);
     delete m;                           // DevBuf destructors release everything
     return VR_OK;
 }
@@ -133,11 +92,13 @@ extern "C" int vg_load_weight(vg_model_t m, const char* name_c, const void* data
     for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
     const int E = m->E, I = m->I, V = m->V, QD = m->QD, KVD = m->KVD, QKV = m->QKV;
     auto bad_shape = [&]() { return fail(VR_ERR_INVALID, "unexpected shape for %s", name_c); };
-    if (name.rfind("model.visual.", 0) == 0 || name.rfind("visual.", 0) == 0) return VR_OK;      // vision tower: not this library's yet
+    const bool vis_key = name.rfind("model.visual.", 0) == 0 || name.rfind("visual.", 0) == 0;
+    if (vis_key && !m->vis) return VR_OK;                  // no tower attached (vg_vision_create): its tensors are skipped
     Staged st;
     VRCHK(stage(data, numel * (bf ? 2 : 4), on_device, st));
     const void* src = st.dev;
     m->finalized = false;
+    if (vis_key) return vision_load_weight(m, name.substr(name.find("visual.") + 7), src, bf, shape, ndim, numel);
     const std::string pre = "model.language_model.";
     if (name == pre + "embed_tokens.weight") {
         if (!shape_is(shape, ndim, {V, E})) return bad_shape();
@@ -193,6 +154,7 @@ extern "C" int vg_finalize(vg_model_t m) {
         if (!l.ln1.ok || !l.ln2.ok || l.parts_w != 7 || l.parts_b != 7 || l.parts_gu != 3 || !l.o.has_w || !l.down.has_w)
             return fail(VR_ERR_STATE, "layer %zu is incomplete", i);
     }
+    if (m->vis) VRCHK(vision_check_complete(m));
     m->finalized = true;
     return VR_OK;
 }
@@ -297,7 +259,9 @@ extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int
     if (!m || !ids || !pos3) return fail(VR_ERR_INVALID, "NULL argument");
     if (!m->finalized) return fail(VR_ERR_STATE, "vg_finalize has not succeeded");
     if (T <= 0 || T > m->c.max_prefill) return fail(VR_ERR_CAPACITY, "%d prompt tokens (max_prefill %d)", T, m->c.max_prefill);
-    if (n_embed < 0 || n_embed > T || (n_embed > 0 && (!embed_rows || !embeds))) return fail(VR_ERR_INVALID, "bad embedding overrides");
+    if (n_embed < 0 || n_embed > T || (n_embed > 0 && !embed_rows)) return fail(VR_ERR_INVALID, "bad embedding overrides");
+    if (n_embed > 0 && !embeds && n_embed != m->vis_tokens)
+        return fail(VR_ERR_STATE, "embeds is NULL: %d rows asked for, the last vg_vision_encode left %d on the device", n_embed, m->vis_tokens);
     for (int i = 0; i < T; ++i)
         if (ids[i] < 0 || ids[i] >= m->V) return fail(VR_ERR_INVALID, "token id %d out of range", ids[i]);
     for (int i = 0; i < n_embed; ++i)
@@ -319,7 +283,10 @@ extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int
     HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
     if (n_embed > 0) {
         HIPCHK(hipMemcpyAsync(m->w_erows.p, embed_rows, (size_t)n_embed * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(m->w_emb.p, embeds, (size_t)n_embed * E * 4, hipMemcpyHostToDevice, s));
+        if (embeds) {
+            HIPCHK(hipMemcpyAsync(m->w_emb.p, embeds, (size_t)n_embed * E * 4, hipMemcpyHostToDevice, s));
+            m->vis_tokens = 0;                                // w_emb no longer holds a tower result
+        }
         HIPCHK(launch_scatter_rows(m->w_emb.as<float>(), m->w_erows.as<int>(), n_embed, E, m->w_h.as<float>(), E, s));
     }
     HIPCHK(hipStreamSynchronize(s));            // the host buffers above may go away after the call

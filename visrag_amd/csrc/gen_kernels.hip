@@ -176,6 +176,20 @@ hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int 
     return hipGetLastError();
 }
 
+// dst[i][:] = bf16(src[row_idx[i]][:]), columns [dim, ld) zero: the vision tower's pixel rows, put into window order
+// and padded to the GEMM's K on their way to bf16 (the dtype the reference's tower receives them in)
+__global__ void gather_rows_bf16_kernel(const float* __restrict__ src, const int* __restrict__ row_idx, int dim,
+                                        bf16_t* __restrict__ dst, int ld) {
+    const int i = blockIdx.x;
+    const float* row = src + (size_t)row_idx[i] * dim;
+    for (int c = threadIdx.x; c < ld; c += blockDim.x) dst[(size_t)i * ld + c] = f2bf(c < dim ? row[c] : 0.f);
+}
+hipError_t launch_gather_rows_bf16(const float* src, const int* row_idx, int n, int dim, void* dst, int ld, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(n), dim3(256), 0, s, src, row_idx, dim, (bf16_t*)dst, ld);
+    return hipGetLastError();
+}
+
 // one decode step's attention was run as S independent KV ranges (attention_kernel with q_shared): merge them
 __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, const float* __restrict__ lse, int S, int heads,
                                     bf16_t* __restrict__ out) {

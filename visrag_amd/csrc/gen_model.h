@@ -1,0 +1,54 @@
+// The EVisRAG generator's model object, shared by gen.hip (language model) and gen_vision.hip (vision tower).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/visrag_gen.h"
+#include "engine_common.h"
+
+struct GenLayer {
+    Vec ln1, ln2;
+    Linear qkv, o, gu, down;
+    int parts_w = 0, parts_b = 0, parts_gu = 0;
+};
+
+constexpr int GEN_KS_MAX = 64;      // split-K planes of the decode path
+constexpr int GEN_ATT_SPLITS = 16;  // most KV ranges one decode step's attention is cut into
+
+struct VisionTower;                 // gen_vision.hip
+
+struct vg_model_s {
+    int device = 0;
+    vg_config_t c{};
+    bool finalized = false;
+    int E = 0, H = 0, KV = 0, I = 0, V = 0, QKV = 0, QD = 0, KVD = 0;
+    DevBuf embed;
+    bool has_embed = false;
+    std::vector<GenLayer> layers;
+    Vec final_norm;
+    Linear lm_head;
+    DevBuf inv_freq;
+    std::vector<DevBuf> kc, vc;          // per layer [max_len][KVD] bf16
+    int len = 0;                         // rows of the cache in use
+    bool have_logits = false;
+    int Tcap = 0;
+    DevBuf w_h, w_xn, w_qkv, w_q, w_att, w_act, w_last, w_part, w_logits, w_ids, w_pos, w_cu, w_seen, w_tok, w_erows, w_emb;
+    DevBuf w_attp, w_lse;               // decode: partial attention rows [GEN_ATT_SPLITS][QD] bf16 + their log-sum-exps
+    int dec_splits = 1;                 // KV ranges of the current decode step (w_cu: cu_q at [0..], cu_kv at [GEN_ATT_SPLITS + 1..])
+    VisionTower* vis = nullptr;         // attached by vg_vision_create
+    int vis_tokens = 0;                 // embedding rows the last vg_vision_encode left in w_emb (image-token order)
+};
+
+static inline GemmArgs gen_gemm_args(const void* A, int lda, const Linear& L, int M, void* out, int ldo) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = L.w.p; a.ldw = L.k_pad; a.M = M; a.N = L.n_pad; a.K = L.k_pad;
+    a.bias = L.has_b ? L.b.as<float>() : nullptr;
+    a.out = out; a.ldo = ldo; a.alpha = 1.0f;
+    return a;
+}
+
+// gen_vision.hip: the tower's side of vg_load_weight / vg_finalize / vg_destroy
+int vision_load_weight(vg_model_s* m, const std::string& key, const void* dev_src, int is_bf16, const int64_t* shape, int ndim,
+                       size_t numel);                 // key without the "model.visual." prefix
+int vision_check_complete(const vg_model_s* m);
+void vision_destroy(vg_model_s* m);

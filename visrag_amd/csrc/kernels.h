@@ -88,6 +88,8 @@ hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hi
 hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
                          unsigned long long seed, unsigned step, int* token_out, unsigned long long* scratch64, hipStream_t s);
 hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int dim, float* dst, int ld, hipStream_t s);
+// dst[i][:] = bf16(src[row_idx[i]][0..dim)), zero up to ld (src rows are dense: stride dim)
+hipError_t launch_gather_rows_bf16(const float* src, const int* row_idx, int n, int dim, void* dst, int ld, hipStream_t s);
 // out[h*128 + d] = sum_s 2^(lse[s][h] - max) * part[s][h*128 + d] / sum_s 2^(lse[s][h] - max): merges the S partial
 // attention rows (bf16 [S][ldp], each normalised over its own KV range) of one decode step
 hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s);

@@ -35,6 +35,36 @@ hipError_t launch_pack_weight(const void* src, int src_is_bf16, int rows, int co
     return hipGetLastError();
 }
 
+// The same with a block map on the columns too: dst[rmap(r)][cmap(c)] = src[r][c], map(x) = (x / blk) * stride + x % blk.
+// (The EVisRAG vision tower gives every head_dim-80 head a 128-wide slot: 40-row blocks of q / k / v at a stride of 64
+// rows, and the matching 40-column blocks of the output projection.)
+template <typename SrcT>
+__global__ __launch_bounds__(256) void pack_weight_blocks_kernel(const SrcT* __restrict__ src, int rows, int cols, int src_ld,
+                                                                 bf16_t* __restrict__ dst, int dst_ld, int rblk, int rstride,
+                                                                 int cblk, int cstride) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const int dr = (r / rblk) * rstride + (r % rblk), dc = (c / cblk) * cstride + (c % cblk);
+        dst[(size_t)dr * dst_ld + dc] = f2bf((float)src[(size_t)r * src_ld + c]);
+    }
+}
+
+hipError_t launch_pack_weight_blocks(const void* src, int src_is_bf16, int rows, int cols, int src_ld, void* dst, int dst_ld,
+                                     int rblk, int rstride, int cblk, int cstride, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (n == 0) return hipSuccess;
+    if (rblk <= 0 || cblk <= 0) return hipErrorInvalidValue;
+    const int blocks = (int)min((size_t)4096, (n + 255) / 256);
+    if (src_is_bf16)
+        hipLaunchKernelGGL(pack_weight_blocks_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, rows, cols, src_ld,
+                           (bf16_t*)dst, dst_ld, rblk, rstride, cblk, cstride);
+    else
+        hipLaunchKernelGGL(pack_weight_blocks_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, rows, cols, src_ld,
+                           (bf16_t*)dst, dst_ld, rblk, rstride, cblk, cstride);
+    return hipGetLastError();
+}
+
 template <typename SrcT>
 __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const SrcT* __restrict__ src, int D, int P,
                                                                 bf16_t* __restrict__ dst, int dst_ld) {
@@ -60,6 +90,22 @@ template <typename SrcT>
 __global__ void to_f32_kernel(const SrcT* __restrict__ src, float* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         dst[i] = (float)src[i];
+}
+
+// dst[(i / blk) * stride + off + i % blk] = src[i]  (bias vectors that follow a block-mapped weight)
+template <typename SrcT>
+__global__ void to_f32_blocks_kernel(const SrcT* __restrict__ src, float* __restrict__ dst, size_t n, int blk, int stride, int off) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dst[(i / blk) * stride + off + i % blk] = (float)src[i];
+}
+
+hipError_t launch_to_f32_blocks(const void* src, int src_is_bf16, float* dst, size_t n, int blk, int stride, int off, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (blk <= 0) return hipErrorInvalidValue;
+    const int blocks = (int)min((size_t)4096, (n + 255) / 256);
+    if (src_is_bf16) hipLaunchKernelGGL(to_f32_blocks_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, dst, n, blk, stride, off);
+    else hipLaunchKernelGGL(to_f32_blocks_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, dst, n, blk, stride, off);
+    return hipGetLastError();
 }
 
 hipError_t launch_to_f32(const void* src, int src_is_bf16, float* dst, size_t n, hipStream_t s) {

@@ -6,11 +6,14 @@
     outs = llm.generate([{"prompt_token_ids": ids, "multi_modal_data": {...}}], sampling_params=sp)   # predict.py:147
     outs[0].outputs[0].token_ids / .text
 
-What this module does NOT contain: the Qwen2.5-VL vision tower and the tokenizer / chat template (the reference gets
-them from the checkpoint directory through `AutoProcessor`; there is no checkpoint on this box).  A prompt is
-therefore token ids, plus — for every image — its embedding rows and grid: `{"image_embeds": [f32 [h*w, hidden], ...],
-"image_grids": [(h, w), ...]}` where h x w is the MERGED token grid of the image; the placeholder tokens
-`image_token_id` in the ids mark where the rows go (one placeholder per row, as the processor expands them).
+What this module does NOT contain: the tokenizer / chat template (the reference gets them from the checkpoint directory
+through `AutoProcessor`; there is no checkpoint on this box).  A prompt is therefore token ids, plus its page images:
+  * `{"image": [PIL.Image, ...]}` like predict.py:140-145 — with a vision tower attached (`LLM(..., vision=VisionConfig())`)
+    the images go through the Qwen2-VL image processing (`process_images`: smart_resize, bicubic resize, normalise,
+    patchify) and the HIP tower; every `image_token_id` in the ids stands for one image (the chat template's single
+    <|image_pad|>) and is expanded to the image's token count, or the ids arrive already expanded;
+  * or precomputed rows: `{"image_embeds": [f32 [h*w, hidden], ...], "image_grids": [(h, w), ...]}` where h x w is the
+    MERGED token grid of the image and the ids hold one placeholder per row.
 Positions follow the reference model's `get_rope_index`: text advances all three axes together; an image keeps the
 temporal axis fixed and runs height / width over its grid; text after it resumes at the largest position so far + 1.
 There is no CPU fallback: without libvisrag_hip.so this module raises.
@@ -40,6 +43,41 @@ class GenConfig:
     mrope_section: Tuple[int, int, int] = (16, 24, 24)
     image_token_id: int = 151655
     eos_token_ids: Tuple[int, ...] = (151645, 151643)
+
+
+@dataclass
+class VisionConfig:
+    """Vision-tower dimensions of Qwen2.5-VL-7B by default (HF Qwen2_5_VLVisionConfig names); min/max_pixels are the
+    image processor's area limits (preprocessor_config.json of the checkpoint)."""
+    depth: int = 32
+    hidden_size: int = 1280
+    num_heads: int = 16
+    intermediate_size: int = 3420
+    out_hidden_size: int = 3584
+    in_channels: int = 3
+    patch_size: int = 14
+    temporal_patch_size: int = 2
+    spatial_merge_size: int = 2
+    window_size: int = 112
+    fullatt_block_indexes: Tuple[int, ...] = (7, 15, 23, 31)
+    rms_norm_eps: float = 1e-6
+    min_pixels: int = 56 * 56
+    max_pixels: int = 28 * 28 * 1280
+    image_mean: Tuple[float, float, float] = (0.48145466, 0.4578275, 0.40821073)
+    image_std: Tuple[float, float, float] = (0.26862954, 0.26130258, 0.27577711)
+
+    @property
+    def patch_dim(self) -> int:
+        return self.in_channels * self.temporal_patch_size * self.patch_size * self.patch_size
+
+    def to_c(self, max_rows: int) -> "_lib.VGVisionConfig":
+        full = list(self.fullatt_block_indexes)
+        if len(full) > 16:
+            raise ValueError("at most 16 full-attention blocks")
+        return _lib.VGVisionConfig(self.depth, self.hidden_size, self.num_heads, self.intermediate_size, self.out_hidden_size,
+                                   self.in_channels, self.patch_size, self.temporal_patch_size, self.spatial_merge_size,
+                                   self.window_size, len(full), (C.c_int32 * 16)(*(full + [0] * (16 - len(full)))), int(max_rows),
+                                   self.rms_norm_eps)
 
 
 @dataclass
@@ -153,6 +191,101 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
                      "bytes_per_token": stream * 2}}
 
 
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 28 * 28 * 1280) -> Tuple[int, int]:
+    """The size the Qwen2-VL image processor resizes a page to: both sides multiples of `factor` (patch x merge), the area
+    within [min_pixels, max_pixels], the aspect ratio kept as closely as the grid allows."""
+    import math
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
+    h = round(height / factor) * factor
+    w = round(width / factor) * factor
+    if h * w > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h = max(factor, math.floor(height / beta / factor) * factor)
+        w = max(factor, math.floor(width / beta / factor) * factor)
+    elif h * w < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h = math.ceil(height * beta / factor) * factor
+        w = math.ceil(width * beta / factor) * factor
+    return h, w
+
+
+def process_images(images, vc: "VisionConfig") -> Tuple[np.ndarray, np.ndarray]:
+    """PIL pages -> (pixel_values f32 [rows][patch_dim], image_grid_thw int32 [n][3]) like the reference's image processor
+    (what vLLM runs on predict.py:140's `image_inputs`): RGB, bicubic resize to smart_resize's size, /255, normalise, cut
+    into patch rows in merge-block-major order, the still image repeated over the temporal patch."""
+    from PIL import Image
+    p, m, tp = vc.patch_size, vc.spatial_merge_size, vc.temporal_patch_size
+    mean = np.asarray(vc.image_mean, dtype=np.float32)
+    std = np.asarray(vc.image_std, dtype=np.float32)
+    rows, grids = [], []
+    for im in images:
+        im = im.convert("RGB")
+        H, W = smart_resize(im.height, im.width, p * m, vc.min_pixels, vc.max_pixels)
+        x = np.asarray(im.resize((W, H), Image.BICUBIC), dtype=np.float32)
+        x = ((x * np.float32(1.0 / 255.0) - mean) / std).transpose(2, 0, 1)                  # [C][H][W]
+        gh, gw = H // p, W // p
+        x = x.reshape(x.shape[0], gh // m, m, p, gw // m, m, p).transpose(1, 4, 2, 5, 0, 3, 6)   # [gh/m][gw/m][m][m][C][p][p]
+        x = np.broadcast_to(x[:, :, :, :, :, None], x.shape[:5] + (tp,) + x.shape[5:])
+        rows.append(np.ascontiguousarray(x).reshape(gh * gw, -1))
+        grids.append((1, gh, gw))
+    return np.ascontiguousarray(np.concatenate(rows), dtype=np.float32), np.asarray(grids, dtype=np.int32)
+
+
+def vision_weight_specs(vc: "VisionConfig"):
+    """HF state-dict keys of the vision tower -> (shape, amplitude, offset) of the synthetic weights (benchmarks)."""
+    import math
+    H, I, P = vc.hidden_size, vc.intermediate_size, vc.patch_size
+    lin = lambda fan_in, g=1.0: g * math.sqrt(3.0 / fan_in)
+    pre = "model.visual."
+    specs = {pre + "patch_embed.proj.weight": ((H, vc.in_channels, vc.temporal_patch_size, P, P), lin(vc.patch_dim), 0.0)}
+    for l in range(vc.depth):
+        b = f"{pre}blocks.{l}."
+        specs[b + "norm1.weight"] = ((H,), 0.1, 1.0)
+        specs[b + "norm2.weight"] = ((H,), 0.1, 1.0)
+        specs[b + "attn.qkv.weight"] = ((3 * H, H), lin(H), 0.0)
+        specs[b + "attn.qkv.bias"] = ((3 * H,), 0.1, 0.0)
+        specs[b + "attn.proj.weight"] = ((H, H), lin(H, 0.5), 0.0)
+        specs[b + "attn.proj.bias"] = ((H,), 0.05, 0.0)
+        specs[b + "mlp.gate_proj.weight"] = ((I, H), lin(H), 0.0)
+        specs[b + "mlp.gate_proj.bias"] = ((I,), 0.1, 0.0)
+        specs[b + "mlp.up_proj.weight"] = ((I, H), lin(H), 0.0)
+        specs[b + "mlp.up_proj.bias"] = ((I,), 0.1, 0.0)
+        specs[b + "mlp.down_proj.weight"] = ((H, I), lin(I, 0.5), 0.0)
+        specs[b + "mlp.down_proj.bias"] = ((H,), 0.05, 0.0)
+    M = H * vc.spatial_merge_size ** 2
+    specs[pre + "merger.ln_q.weight"] = ((H,), 0.1, 1.0)
+    specs[pre + "merger.mlp.0.weight"] = ((M, M), lin(M), 0.0)
+    specs[pre + "merger.mlp.0.bias"] = ((M,), 0.1, 0.0)
+    specs[pre + "merger.mlp.2.weight"] = ((vc.out_hidden_size, M), lin(M, 0.25), 0.0)
+    specs[pre + "merger.mlp.2.bias"] = ((vc.out_hidden_size,), 0.02, 0.0)
+    return specs
+
+
+def iter_synth_vision_weights(vc: "VisionConfig", seed: int = 0, device="cpu", bf16: bool = False):
+    from .synth import synth_tensor
+    import torch
+    for k, (shape, amp, off) in vision_weight_specs(vc).items():
+        t = synth_tensor(k, shape, amp, seed, off, device=device)
+        yield k, (t.to(torch.bfloat16) if bf16 else t)
+
+
+def vision_plan(vc: "VisionConfig", grid_thw) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(order [tokens], window row boundaries, hw [rows][2]) the tower uses for these grids — host-only entry point of the
+    library (vg_vision_plan), for tests."""
+    g = np.ascontiguousarray(grid_thw, dtype=np.int32).reshape(-1, 3)
+    rows = int((g[:, 0] * g[:, 1] * g[:, 2]).sum())
+    tokens = rows // vc.spatial_merge_size ** 2
+    order = np.zeros(tokens, np.int32)
+    bounds = np.zeros(tokens + 1, np.int32)
+    hw = np.zeros((rows, 2), np.int32)
+    nw = C.c_int32()
+    cfg = vc.to_c(max(rows, 1))
+    _lib.check(_lib.load().vg_vision_plan(C.byref(cfg), C.c_void_p(g.ctypes.data), len(g), C.c_void_p(order.ctypes.data),
+                                          C.c_void_p(bounds.ctypes.data), C.byref(nw), C.c_void_p(hw.ctypes.data)), "vg_vision_plan")
+    return order, bounds[:nw.value + 1], hw
+
+
 def rope_index(ids: Sequence[int], image_token_id: int, grids: Sequence[Tuple[int, int]]) -> np.ndarray:
     """[3][T] temporal / height / width positions of a prompt whose images are runs of `image_token_id`, one run of
     h*w placeholders per (h, w) in `grids`, in order (Qwen2.5-VL get_rope_index for still images)."""
@@ -188,7 +321,8 @@ class LLM:
 
     def __init__(self, model, tensor_parallel_size: int = 1, dtype: str = "bfloat16",
                  limit_mm_per_prompt: Optional[Dict[str, int]] = None, max_model_len: int = 8192, max_prefill: int = 4096,
-                 device: int = 0, weights=None, detokenize: Optional[Callable[[List[int]], str]] = None):
+                 device: int = 0, weights=None, detokenize: Optional[Callable[[List[int]], str]] = None,
+                 vision: Optional[VisionConfig] = None, max_vision_rows: Optional[int] = None):
         if tensor_parallel_size != 1:
             raise ValueError("one GPU per model (predict.py:114 uses tensor_parallel_size=1)")
         if dtype not in ("bfloat16", "bf16"):
@@ -208,6 +342,16 @@ class LLM:
         h = C.c_void_p()
         _lib.check(self._lib.vg_create(self.device, C.byref(vc), C.byref(h)), "vg_create")
         self._h = h
+        self.vision = vision
+        if vision is not None:
+            if vision.out_hidden_size != c.hidden_size:
+                raise ValueError("vision.out_hidden_size must equal the language model's hidden_size")
+            m2 = vision.spatial_merge_size ** 2
+            # default: every image at the processor's largest size, capped by what a prefill can take
+            rows = max_vision_rows or min(self.max_images * (vision.max_pixels // vision.patch_size ** 2), self.max_prefill * m2)
+            self.max_vision_rows = rows // m2 * m2
+            vcfg = vision.to_c(self.max_vision_rows)
+            _lib.check(self._lib.vg_vision_create(self._h, C.byref(vcfg)), "vg_vision_create")
         if weights is not None:
             self.load_weights(weights)
 
@@ -234,6 +378,58 @@ class LLM:
             self.close()
         except Exception:
             pass
+
+    # ---- images ------------------------------------------------------------------------------------------
+    def encode_images(self, pixel_values: np.ndarray, image_grid_thw: np.ndarray, fetch: bool = True) -> Optional[np.ndarray]:
+        """The vision tower on the processor's output: [tokens][hidden] embedding rows, image by image (also kept on the
+        device for the next prefill)."""
+        if self.vision is None:
+            raise RuntimeError("this LLM has no vision tower (LLM(..., vision=VisionConfig()))")
+        px = np.ascontiguousarray(pixel_values, dtype=np.float32)
+        g = np.ascontiguousarray(image_grid_thw, dtype=np.int32).reshape(-1, 3)
+        rows = int((g[:, 0] * g[:, 1] * g[:, 2]).sum())
+        if px.shape != (rows, self.vision.patch_dim):
+            raise ValueError(f"pixel_values {px.shape} for grids that hold {rows} x {self.vision.patch_dim}")
+        out = np.empty((rows // self.vision.spatial_merge_size ** 2, self.cfg.hidden_size), dtype=np.float32) if fetch else None
+        _lib.check(self._lib.vg_vision_encode(self._h, C.c_void_p(px.ctypes.data), C.c_void_p(g.ctypes.data), len(g),
+                                              C.c_void_p(out.ctypes.data) if fetch else None, None), "vg_vision_encode")
+        return out
+
+    def expand_image_tokens(self, ids: Sequence[int], token_counts: Sequence[int]) -> List[int]:
+        """One placeholder per image (the chat template's <|image_pad|>) -> one per image token, like the processor does;
+        ids that already hold sum(token_counts) placeholders pass through."""
+        tid = self.cfg.image_token_id
+        n = sum(1 for t in ids if t == tid)
+        if n == sum(token_counts):
+            return list(ids)
+        if n != len(token_counts):
+            raise ValueError(f"{n} image placeholders for {len(token_counts)} images ({sum(token_counts)} image tokens)")
+        out, k = [], 0
+        for t in ids:
+            if t == tid:
+                out += [tid] * token_counts[k]
+                k += 1
+            else:
+                out.append(t)
+        return out
+
+    def prefill_images(self, ids: Sequence[int], pixel_values: np.ndarray, image_grid_thw: np.ndarray) -> Tuple[np.ndarray, List[int]]:
+        """Tower + prefill with the embedding rows staying on the device.  Returns (positions, expanded ids)."""
+        c, m = self.cfg, self.vision.spatial_merge_size
+        g = np.ascontiguousarray(image_grid_thw, dtype=np.int32).reshape(-1, 3)
+        if len(g) > self.max_images:
+            raise ValueError(f"{len(g)} images (limit {self.max_images})")
+        grids = [(int(h) // m, int(w) // m) for _, h, w in g]
+        if any(int(t) != 1 for t, _, _ in g):
+            raise ValueError("still images only (predict.py:116 sets the video limit to 0)")
+        ids = self.expand_image_tokens(ids, [h * w for h, w in grids])
+        self.encode_images(pixel_values, g, fetch=False)
+        ids_a = np.ascontiguousarray(ids, dtype=np.int32)
+        pos3 = np.ascontiguousarray(rope_index(list(ids_a), c.image_token_id, grids), dtype=np.int32)
+        rows = np.nonzero(ids_a == c.image_token_id)[0].astype(np.int32)
+        _lib.check(self._lib.vg_prefill(self._h, C.c_void_p(ids_a.ctypes.data), len(ids_a), C.c_void_p(rows.ctypes.data), None,
+                                        len(rows), C.c_void_p(pos3.ctypes.data), None), "vg_prefill")
+        return pos3, ids
 
     # ---- one sequence ------------------------------------------------------------------------------------
     def prefill(self, ids: Sequence[int], image_embeds: Sequence[np.ndarray] = (), image_grids: Sequence[Tuple[int, int]] = (),
@@ -279,7 +475,14 @@ class LLM:
         for pr in prompts:
             ids = list(pr["prompt_token_ids"])
             mm = pr.get("multi_modal_data") or {}
-            pos3 = self.prefill(ids, mm.get("image_embeds", ()), mm.get("image_grids", ()), pr.get("positions"))
+            if mm.get("image") is not None or mm.get("pixel_values") is not None:
+                if self.vision is None:
+                    raise RuntimeError("images need a vision tower: LLM(..., vision=VisionConfig())")
+                px, grid = (mm["pixel_values"], mm["image_grid_thw"]) if mm.get("pixel_values") is not None \
+                    else process_images(mm["image"], self.vision)
+                pos3, ids = self.prefill_images(ids, px, grid)
+            else:
+                pos3 = self.prefill(ids, mm.get("image_embeds", ()), mm.get("image_grids", ()), pr.get("positions"))
             nxt = int(pos3.max()) + 1
             toks: List[int] = []
             room = self.max_model_len - len(ids)
