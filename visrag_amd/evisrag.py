@@ -137,17 +137,24 @@ def iter_synth_gen_weights(cfg: "GenConfig", seed: int = 0, device="cpu", bf16: 
         yield k, (t.to(torch.bfloat16) if bf16 else t)
 
 
-def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2, device: int = 0) -> dict:
+def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2, device: int = 0, vision: bool = True) -> dict:
     """EVisRAG-7B-shaped generation (BASELINE config 5: the top retrieved pages go to the generator, one query at a
-    time like src/evisrag/predict.py:128-149): random weights of the Qwen2.5-VL-7B language model, image tokens as
-    precomputed embedding rows (16 x 16 merged tokens per 448 x 448 page).  Returns prefill / decode timings, the
-    queries/s for this answer length and the decode step's weight-streaming rate against the HBM."""
+    time like src/evisrag/predict.py:128-149): random weights of Qwen2.5-VL-7B (vision tower + language model), pages
+    as the image processor's pixel rows (448 x 448: 32 x 32 patches -> 16 x 16 image tokens).  Returns vision / prefill
+    / decode timings, the queries/s for this answer length and the decode step's weight-streaming rate against the
+    HBM.  vision=False: image tokens as precomputed embedding rows, language model only."""
+    import itertools
     import time
     import torch
     cfg = GenConfig()
+    vc = VisionConfig() if vision else None
     t0 = time.time()
-    llm = LLM(cfg, limit_mm_per_prompt={"image": max(5, n_images)}, max_model_len=4096, max_prefill=2048, device=device)
-    llm.load_weights(iter_synth_gen_weights(cfg, 0, device=f"cuda:{device}", bf16=True))
+    llm = LLM(cfg, limit_mm_per_prompt={"image": max(5, n_images)}, max_model_len=4096, max_prefill=2048, device=device, vision=vc,
+              max_vision_rows=n_images * 1024 if vision else None)
+    w = iter_synth_gen_weights(cfg, 0, device=f"cuda:{device}", bf16=True)
+    if vision:
+        w = itertools.chain(w, iter_synth_vision_weights(vc, 0, device=f"cuda:{device}", bf16=True))
+    llm.load_weights(w)
     torch.cuda.synchronize(device)
     t_load = time.time() - t0
     specs = gen_weight_specs(cfg)
@@ -161,12 +168,39 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
     ids += [int(t) for t in rng.integers(1000, 50000, 60)]
     embs = [(rng.standard_normal((grid[0] * grid[1], cfg.hidden_size)) * 0.05).astype(np.float32) for _ in range(n_images)]
     sp = SamplingParams(temperature=0.1, repetition_penalty=1.05, max_tokens=answer_tokens, stop_token_ids=())
-    llm.generate([{"prompt_token_ids": ids, "multi_modal_data": {"image_embeds": embs, "image_grids": [grid] * n_images}}],
+    mm = {"image_embeds": embs, "image_grids": [grid] * n_images}
+    vis_ms, vis_tf = None, None
+    if vision:
+        px = (rng.standard_normal((n_images * 1024, vc.patch_dim))).astype(np.float32)
+        thw = np.asarray([(1, 32, 32)] * n_images, dtype=np.int32)
+        mm = {"pixel_values": px, "image_grid_thw": thw}
+    llm.generate([{"prompt_token_ids": ids, "multi_modal_data": mm}],
                  SamplingParams(temperature=0.1, repetition_penalty=1.05, max_tokens=4, stop_token_ids=()))      # warm-up
+    if vision:
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(device); a = time.perf_counter()
+            llm.encode_images(px, thw, fetch=False)
+            torch.cuda.synchronize(device); ts.append(time.perf_counter() - a)
+        vis_ms = float(np.median(ts)) * 1e3
+        vspecs = vision_weight_specs(vc)
+        R = px.shape[0]
+        blk = sum(int(np.prod(sh)) for k, (sh, _, _) in vspecs.items() if ".blocks." in k and k.endswith("weight") and len(sh) == 2)
+        mrg = sum(int(np.prod(sh)) for k, (sh, _, _) in vspecs.items() if ".merger.mlp." in k and k.endswith("weight"))
+        hd = vc.hidden_size // vc.num_heads
+        att = 0.0                                            # QK^T + PV: 4 x rows x keys x hidden per block
+        for l in range(vc.depth):
+            keys = 1024 if l in vc.fullatt_block_indexes else 64
+            att += 4.0 * R * keys * vc.hidden_size
+        flop = 2.0 * R * (blk + vc.hidden_size * vc.patch_dim) + 2.0 * (R / 4) * mrg + att
+        vis_tf = flop / (vis_ms * 1e-3) / 1e12
     pre, dec, tot = [], [], []
     for _ in range(queries):
         torch.cuda.synchronize(device); a = time.perf_counter()
-        pos3 = llm.prefill(ids, embs, [grid] * n_images)
+        if vision:
+            pos3, _ = llm.prefill_images(ids, px, thw)
+        else:
+            pos3 = llm.prefill(ids, embs, [grid] * n_images)
         tok = llm.sample(sp, 0)
         torch.cuda.synchronize(device); b = time.perf_counter()
         nxt = int(pos3.max()) + 1
@@ -178,11 +212,13 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
     llm.close()
     T, p_s, d_s = len(ids), float(np.median(pre)), float(np.median(dec))
     return {
-        "workload": f"Qwen2.5-VL-7B-shaped language model, bf16, random weights; prompt {T} tokens ({n_images} pages x 256 image tokens "
-                    f"as embedding rows + text), {answer_tokens} answer tokens, temperature 0.1, repetition_penalty 1.05, one query "
-                    "at a time; vision tower not included",
+        "workload": f"Qwen2.5-VL-7B-shaped model, bf16, random weights; prompt {T} tokens ({n_images} pages x 256 image tokens "
+                    + ("from the vision tower on 448 x 448 pages (1024 patch rows each, host pixel rows in)" if vision else "as embedding rows")
+                    + f" + text), {answer_tokens} answer tokens, temperature 0.1, repetition_penalty 1.05, one query at a time",
         "params_billion": round(params / 1e9, 3), "load_s": round(t_load, 1),
-        "prefill_ms": round(p_s * 1e3, 2), "prefill_tokens_per_s": round(T / p_s), "prefill_tflops": round(2.0 * stream * T / p_s / 1e12, 1),
+        "vision_ms": round(vis_ms, 2) if vision else None, "vision_tflops": round(vis_tf, 1) if vision else None,
+        "prefill_ms": round(p_s * 1e3, 2), "prefill_includes_vision": bool(vision),
+        "prefill_tokens_per_s": round(T / p_s), "prefill_tflops": round(2.0 * stream * T / (p_s - (vis_ms or 0.0) * 1e-3) / 1e12, 1),
         "decode_ms_per_token": round(d_s * 1e3, 3), "decode_tokens_per_s": round(1.0 / d_s, 1),
         "queries_per_s": round(1.0 / float(np.median(tot)), 3),
         "queries_per_s_at_2048_tokens": round(1.0 / (p_s + 2047 * d_s), 4),
