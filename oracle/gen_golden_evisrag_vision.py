@@ -15,6 +15,8 @@ Stored:
   * the tower's merged embedding rows for the three images in one call, and its per-row hidden state before the merger;
   * the whole model's last-token logits for a prompt "text, image 0, text, image 1, image 2, text" with HF's own
     get_rope_index positions — pins the placeholder replacement and the positions visrag_amd.evisrag.rope_index gives.
+A second file, tests/golden/evisrag_vision_hd80.npz: a tower with the 7B model's head_dim 80 (hd80_vision_config), four
+pages, embedding rows only.
 """
 import os
 import sys
@@ -24,7 +26,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.qwen_gen_oracle import synth_weights, tiny_config  # noqa: E402
-from oracle.qwen_vision_oracle import synth_vision_weights, tiny_vision_config  # noqa: E402
+from oracle.qwen_vision_oracle import hd80_vision_config, synth_vision_weights, tiny_vision_config  # noqa: E402
 
 IMAGE_TOKEN, VISION_START, VISION_END = 5, 6, 7
 
@@ -105,6 +107,25 @@ def main():
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "evisrag_vision_tiny.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), {k: v.shape for k, v in out.items() if not k.startswith("w:")})
+
+    # 4. a tower with the 7B model's head_dim 80 (its own attention-kernel configuration in the product): tower only
+    v80 = hd80_vision_config(cfg.hidden_size)
+    w80 = synth_vision_weights(v80, seed=29)
+    wl = dict(synth_weights(cfg, seed=7))
+    wl.update(w80)
+    m80 = build_hf(cfg, v80, wl)
+    grids80 = [(1, 10, 6), (1, 4, 8), (1, 2, 2), (1, 18, 12)]       # the last one: 216 rows, several tiles of full attention
+    rows80 = sum(t * h * ww for t, h, ww in grids80)
+    px80 = torch.randn((rows80, v80.patch_dim), generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        vo80 = m80.model.visual(px80.float(), grid_thw=torch.tensor(grids80))
+    out80 = {"grids": np.array(grids80, dtype=np.int32), "pixels_bf16": px80.view(torch.int16).numpy(),
+             "image_embeds": vo80.pooler_output.numpy().astype(np.float32)}
+    for k, v in w80.items():
+        out80["w:" + k] = v.to(torch.bfloat16).view(torch.int16).numpy()
+    dst80 = os.path.join(os.path.dirname(dst), "evisrag_vision_hd80.npz")
+    np.savez_compressed(dst80, **out80)
+    print("wrote", dst80, os.path.getsize(dst80))
 
 
 if __name__ == "__main__":

@@ -64,6 +64,12 @@ def tiny_vision_config(out_hidden_size: int = 256) -> QwenVisionConfig:
                             window_size=56, fullatt_block_indexes=(1,))
 
 
+def hd80_vision_config(out_hidden_size: int = 256) -> QwenVisionConfig:
+    """A second fixture tower with the 7B tower's head_dim (80): 2 blocks, the second one attending over whole images."""
+    return QwenVisionConfig(depth=2, hidden_size=160, num_heads=2, intermediate_size=216, out_hidden_size=out_hidden_size,
+                            window_size=56, fullatt_block_indexes=(1,))
+
+
 PREFIX = "model.visual."
 
 

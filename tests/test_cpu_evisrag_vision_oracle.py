@@ -8,8 +8,8 @@ import pytest
 import torch
 
 from oracle.qwen_gen_oracle import QwenGenOracle, synth_weights, tiny_config
-from oracle.qwen_vision_oracle import (QwenVisionOracle, image_bounds, patchify, position_hw, smart_resize, tiny_vision_config,
-                                       vision_weight_specs, window_order)
+from oracle.qwen_vision_oracle import (QwenVisionOracle, hd80_vision_config, image_bounds, patchify, position_hw, smart_resize,
+                                       tiny_vision_config, vision_weight_specs, window_order)
 from visrag_amd.evisrag import rope_index
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "evisrag_vision_tiny.npz")
@@ -43,6 +43,13 @@ def test_tower_embeddings_match_hf():
     order, _ = window_order(_grids(g), o.cfg)
     perm = (order[:, None] * 4 + torch.arange(4)[None]).reshape(-1)
     np.testing.assert_allclose(rows[perm].numpy(), g["tower_rows_window_order"], rtol=2e-4, atol=2e-5)
+
+
+def test_hd80_tower_embeddings_match_hf():
+    g = np.load(os.path.join(os.path.dirname(GOLD), "evisrag_vision_hd80.npz"))
+    o = QwenVisionOracle(hd80_vision_config(), _weights(g))
+    emb = o.forward(_pixels(g), _grids(g))
+    np.testing.assert_allclose(emb.numpy(), g["image_embeds"], rtol=2e-4, atol=2e-5)
 
 
 def test_window_order_geometry():

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle.qwen_gen_oracle import QwenGenOracle, synth_weights, tiny_config
-from oracle.qwen_vision_oracle import QwenVisionOracle, tiny_vision_config
+from oracle.qwen_vision_oracle import QwenVisionOracle, hd80_vision_config, tiny_vision_config
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "evisrag_vision_tiny.npz")
@@ -56,6 +56,29 @@ def test_tower_embeddings_match_hf(setup):
     assert emb.shape == g["image_embeds"].shape
     # bf16 GEMM operands and attention probabilities against HF's fp32 run; fp32 residual stream and accumulation
     _close(emb, g["image_embeds"], 2e-2, 1 - 1e-3)
+
+
+def test_tower_with_head_dim_80_matches_hf():
+    """The 7B tower's head_dim runs on the attention kernel's own head_dim-80 form (no 128-wide slots): a second HF
+    fixture, four pages incl. one whose full-attention block spans several key tiles."""
+    from visrag_amd.evisrag import LLM, GenConfig, VisionConfig
+    g = np.load(os.path.join(os.path.dirname(GOLD), "evisrag_vision_hd80.npz"))
+    cfg, vcfg = tiny_config(), hd80_vision_config(256)
+    gc = GenConfig(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                   num_key_value_heads=cfg.num_key_value_heads, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
+                   rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, mrope_section=tuple(cfg.mrope_section), image_token_id=5,
+                   eos_token_ids=())
+    vc = VisionConfig(depth=vcfg.depth, hidden_size=vcfg.hidden_size, num_heads=vcfg.num_heads, intermediate_size=vcfg.intermediate_size,
+                      out_hidden_size=vcfg.out_hidden_size, window_size=vcfg.window_size,
+                      fullatt_block_indexes=tuple(vcfg.fullatt_block_indexes))
+    w = dict(synth_weights(cfg, seed=7))
+    w.update(_vision_weights(g))
+    llm = LLM(gc, max_model_len=512, max_prefill=256, vision=vc, max_vision_rows=512, weights=w)
+    try:
+        emb = llm.encode_images(_pixels(g), g["grids"])
+        _close(emb, g["image_embeds"], 2e-2, 1 - 1e-3)
+    finally:
+        llm.close()
 
 
 def test_tower_per_image_equals_batched(setup):

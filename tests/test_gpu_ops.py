@@ -152,7 +152,8 @@ def _ref_attn(q, k, v, causal, scale):
 
 @pytest.mark.parametrize("hd,heads,lens,causal", [
     (72, 3, [64, 64], False), (72, 2, [1024], False), (72, 2, [1026, 60], False),
-    (64, 3, [68, 13, 130, 1], True), (64, 2, [700], True), (128, 2, [1024, 60], False)])
+    (64, 3, [68, 13, 130, 1], True), (64, 2, [700], True), (128, 2, [1024, 60], False),
+    (80, 2, [1024, 60], False), (80, 3, [64, 32, 64, 16, 4, 240], False), (80, 2, [700, 130], True)])   # 80: the EVisRAG vision tower
 def test_attention(hd, heads, lens, causal):
     q_shared = hd == 128
     B = len(lens)

@@ -55,6 +55,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int HD> struct AttnCfg;
 template <> struct AttnCfg<64>  { static constexpr int K32 = 2, TAIL = 0, DFRAGS = 4, PITCH = 160; };
 template <> struct AttnCfg<72>  { static constexpr int K32 = 2, TAIL = 1, DFRAGS = 5, PITCH = 160; };
+// head_dim 80 (the EVisRAG vision tower): the 72 form with every byte of the 160-byte row in use — the tail MFMA
+// carries d = 64..79 (two of Q's four k-slots), and there is no spare V column for the row sums (VALU, like 64 / 128)
+template <> struct AttnCfg<80>  { static constexpr int K32 = 2, TAIL = 1, DFRAGS = 5, PITCH = 160; };
 template <> struct AttnCfg<128> { static constexpr int K32 = 4, TAIL = 0, DFRAGS = 8, PITCH = 288; };
 
 constexpr int ATT_KV = 64;          // keys per tile
@@ -84,6 +87,8 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
     using C = AttnCfg<HD>;
     constexpr int K32 = C::K32, DFRAGS = C::DFRAGS, PITCH = C::PITCH;
     constexpr bool TAIL = C::TAIL != 0;
+    constexpr bool ONES = TAIL && DFRAGS * 16 > HD;    // a spare V column holds 1.0: the PV MFMA produces the row sums
+    constexpr int TAILQ = (HD - K32 * 32) / 8;         // 16-byte chunks of real data in the tail window
     constexpr int CPR = HD / 8;                   // 16-byte chunks per global row
     constexpr int QT = 64 * QF;                   // query rows per workgroup
     constexpr int NCH = (ATT_KV * CPR + 255) / 256;   // staging chunks per thread
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
         // tail MFMA (d = 64..95 window): lanes fq == 0 carry the real d = 64..71, every other k-slot of Q
         // is zero — so the K operand of those slots may be ANY finite LDS content (see scores())
         u32x4 rt = {0, 0, 0, 0};
-        if (TAIL && ok && fq == 0) rt = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + K32 * 32);
+        if (TAIL && ok && fq < TAILQ) rt = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 8);
         qtail[f] = __builtin_bit_cast(bf16x8, rt);
     }
 
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
                 const float m_new = upd ? mxs : m_run[f];
                 const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[f] - m_new);
                 m_run[f] = m_new;
-                if constexpr (!TAIL) l_run[f] *= alpha;
+                if constexpr (!ONES) l_run[f] *= alpha;
 #pragma unroll
                 for (int d = 0; d < DFRAGS; ++d) o[f][d] *= alpha;
             }
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[f][kf][r] = __builtin_amdgcn_exp2f(fmaf(s[f][kf][r], sc, neg_m[f]));
-            if constexpr (!TAIL) {
+            if constexpr (!ONES) {
                 float rs = 0.f;
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf) rs += (s[f][kf][0] + s[f][kf][1]) + (s[f][kf][2] + s[f][kf][3]);
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
     };
 
     auto set_ones = [&]() {   // V column HD (= 72) := 1.0 in every key row of every slot
-        if constexpr (TAIL) {
+        if constexpr (ONES) {
             if (tid < NB * ATT_KV) *reinterpret_cast<bf16_t*>(Vs + tid * PITCH + HD * 2) = (bf16_t)1.0f;
         }
     };
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
     for (int f = 0; f < QF; ++f) {
         const int q = qs + (wave * QF + f) * 16 + fr;
         float l = l_run[f];
-        if constexpr (TAIL) l = __shfl(o[f][DFRAGS - 1][0], 32 + fr, 64);   // O^T[72][q]: lane (fq=2, fr=q), reg 0 (all lanes active here)
+        if constexpr (ONES) l = __shfl(o[f][DFRAGS - 1][0], 32 + fr, 64);   // O^T[72][q]: lane (fq=2, fr=q), reg 0 (all lanes active here)
         if (q >= q_len) continue;
         if (p.lse && fq == 0) p.lse[(size_t)(q_row0 + q) * p.heads + h] = m_run[f] + __log2f(l);     // sum_k 2^(s_k * sc) = 2^m * l
         const float inv = 1.0f / l;
@@ -565,6 +570,9 @@ hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
         case 72:
             if (tiny) return big ? launch_t<72, 2, 0>(a, s) : launch_t<72, 1, 0>(a, s);
             return launch_t<72, VR_ATTN_QF, VR_ATTN_PIPE>(a, s);
+        case 80:
+            if (tiny) return big ? launch_t<80, 2, 0>(a, s) : launch_t<80, 1, 0>(a, s);
+            return launch_t<80, VR_ATTN_QF, VR_ATTN_PIPE>(a, s);
         case 128: return launch_t<128, 1, 0>(a, s);
         default:  return hipErrorInvalidValue;
     }

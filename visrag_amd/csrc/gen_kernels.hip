@@ -84,6 +84,46 @@ hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_pa
     return hipGetLastError();
 }
 
+// ---- the vision tower's 2-D rotary embedding (gen_vision.hip) -------------------------------------------------
+// Per call: cs[t][p] = (cos, sin)(pos * freq[p]) with pos = the row's h coordinate for p < sec_h, its w coordinate
+// beyond; the same for all 32 blocks and all heads, so it is computed once (R x 64 sincosf) instead of per head slot.
+__global__ void rope2d_table_kernel(const int* __restrict__ pos_h, const int* __restrict__ pos_w, int T, int sec_h,
+                                    const float* __restrict__ freq, float2* __restrict__ cs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * 64) return;
+    const int t = i >> 6, p = i & 63;
+    const float ang = (float)(p < sec_h ? pos_h[t] : pos_w[t]) * freq[p];
+    cs[i] = float2{cosf(ang), sinf(ang)};
+}
+hipError_t launch_rope2d_table(const int* pos_h, const int* pos_w, int T, int sec_h, const float* freq, void* cs, hipStream_t s) {
+    if (T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rope2d_table_kernel, dim3((T * 64 + 255) / 256), dim3(256), 0, s, pos_h, pos_w, T, sec_h, freq, (float2*)cs);
+    return hipGetLastError();
+}
+
+// Per block: q and k heads rotated IN PLACE in the qkv rows (head slots of 2 * hh columns, lane p < hh holds the
+// rotate-half pair (p, p + hh)); v is not touched — the attention kernel reads all three straight from the qkv buffer.
+// One wave per (row, head slot), slots [0, n_slots) = the q heads then the k heads (contiguous columns).
+__global__ __launch_bounds__(256) void rope2d_inplace_kernel(bf16_t* __restrict__ qkv, int ld, int T, int n_slots, int hh,
+                                                             const float2* __restrict__ cs) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= T * n_slots || lane >= hh) return;
+    const int t = slot / n_slots, hs = slot - t * n_slots;
+    bf16_t* row = qkv + (size_t)t * ld + hs * 2 * hh;
+    const float2 c = cs[t * 64 + lane];
+    const float x1 = bf2f(row[lane]), x2 = bf2f(row[hh + lane]);
+    row[lane] = f2bf(x1 * c.x - x2 * c.y);                                               // x*cos + rotate_half(x)*sin
+    row[hh + lane] = f2bf(x2 * c.x + x1 * c.y);
+}
+hipError_t launch_rope2d_inplace(void* qkv, int ld, int T, int n_slots, int hh, const void* cs, hipStream_t s) {
+    if (T <= 0 || n_slots <= 0) return hipSuccess;
+    if (hh <= 0 || hh > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rope2d_inplace_kernel, dim3((T * n_slots + 3) / 4), dim3(256), 0, s, (bf16_t*)qkv, ld, T, n_slots, hh,
+                       (const float2*)cs);
+    return hipGetLastError();
+}
+
 // seen[id / 32] |= 1 << (id % 32) for the prompt's token ids (the repetition penalty covers prompt and output)
 __global__ void mark_seen_kernel(const int* __restrict__ ids, int n, unsigned* __restrict__ seen, int vocab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

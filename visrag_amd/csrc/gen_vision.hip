@@ -11,13 +11,14 @@
 //   * rows are put into WINDOW ORDER once, while the pixel rows are converted to bf16 (gather_rows_bf16), so every
 //     attention segment — a window or an image — is a contiguous row range handed to the flash-attention kernel as
 //     cu_q / cu_kv; the merger's output is scattered back into image order straight into the prefill's embedding rows.
-//   * head_dim is 80 (7B) — not a size the attention kernel has.  Every head gets a 128-wide slot instead: the q / k / v
-//     weight rows of a head are packed as two 40-row halves at slot rows [0, 40) and [64, 104) (zeros elsewhere) and the
-//     output projection's columns likewise, so rotate-half pairs (c, c + 40) land on the kernel's pairs (p, p + 64),
-//     the padded channels are exact zeros through q.k and p.v, and the softmax scale stays 1/sqrt(80).  Costs 1.6x
-//     the attention-side FLOPs of a native head_dim-80 kernel; the MLP (2/3 of the tower's FLOPs) is unaffected.
-//   * the rotary kernel is the language model's (mrope_cache_kernel) with a frequency table that repeats the tower's
-//     head_dim/4 frequencies for the height and the width half and sections (0, head_dim/4, rest).
+//   * head_dim 80 (7B), 64 and 128 run on the attention kernel's own configurations.  Any other head_dim (a multiple
+//     of 4 up to 128; the test fixture's 40) gets a 128-wide slot per head: the q / k / v weight rows of a head are
+//     packed as two halves at slot rows [0, hd/2) and [64, 64 + hd/2) (zeros elsewhere) and the output projection's
+//     columns likewise, so rotate-half pairs (c, c + hd/2) land on slot pairs (p, p + 64), the padded channels are
+//     exact zeros through q.k and p.v, and the softmax scale stays 1/sqrt(hd).
+//   * rotary: the (cos, sin) of every row and slot pair is the same for all blocks and heads — computed once per call
+//     (rope2d_table_kernel), then each block rotates its q and k heads in place in the qkv rows and the attention kernel
+//     reads q, k and v straight from that buffer (one row stride for all three): no q / k / v copies.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -47,7 +48,8 @@ struct VisPlan {
 
 struct VisionTower {
     vg_vision_config_t c{};
-    int H = 0, Hp = 0, heads = 0, hd = 0, half = 0, AD = 0, I = 0, Ip = 0, PD = 0, PDp = 0, m2 = 0, MH = 0, MHp = 0;
+    int H = 0, Hp = 0, heads = 0, hd = 0, half = 0, hh = 0, AD = 0, QKVp = 0, ATp = 0, I = 0, Ip = 0, PD = 0, PDp = 0, m2 = 0, MH = 0, MHp = 0;
+    // (hh: distance of a rotate-half pair inside a head slot = half the slot width; AD = heads x slot width)
     int Rcap = 0;
     std::vector<bool> full;
     Linear patch;
@@ -55,7 +57,7 @@ struct VisionTower {
     Vec ln_q;
     Linear mlp0, mlp2;
     DevBuf inv_freq;
-    DevBuf w_pix, w_px, w_x, w_xn, w_qkv, w_q, w_k, w_v, w_att, w_act, w_mid, w_out, w_perm, w_pos, w_cuw, w_cui, w_order;
+    DevBuf w_pix, w_px, w_x, w_xn, w_qkv, w_cs, w_att, w_act, w_mid, w_out, w_perm, w_pos, w_cuw, w_cui, w_order;
 };
 
 // The window order of HF's get_vision_window_index (transformers/vision_utils.py:130-188) and the (h, w) coordinates of
@@ -147,14 +149,16 @@ extern "C" int vg_vision_create(vg_model_t m, const vg_vision_config_t* cfg) {
     auto bail = [&](int rc) { vision_destroy(m); return rc; };
     v->c = c;
     v->H = c.hidden_size; v->Hp = pad128(v->H); v->heads = c.num_heads; v->hd = v->H / v->heads; v->half = v->hd / 2;
-    v->AD = v->heads * 128;
+    v->hh = (v->hd == 64 || v->hd == 80 || v->hd == 128) ? v->half : 64;      // native attention head_dim, or a 128-wide slot
+    v->AD = v->heads * 2 * v->hh;
+    v->QKVp = pad128(3 * v->AD); v->ATp = pad128(v->AD);                       // row strides of the qkv / attention-output rows
     v->I = c.intermediate_size; v->Ip = pad128(v->I);
     v->PD = c.in_channels * c.temporal_patch_size * c.patch_size * c.patch_size; v->PDp = pad128(v->PD);
     v->m2 = m2; v->MH = m2 * v->H; v->MHp = pad128(v->MH);
     v->blocks.resize(c.depth);
     v->full.assign(c.depth, false);
     for (int i = 0; i < c.n_fullatt; ++i) v->full[c.fullatt_blocks[i]] = true;
-    // rotary table for mrope_cache_kernel: lane p < 64 rotates slot channels (p, p + 64) by pos * table[p].  Tower:
+    // rotary frequencies: lane p < 64 rotates slot channels (p, p + 64) by pos * table[p].  Tower:
     // channel pair j < hd/4 turns with the row's h coordinate, hd/4 <= j < hd/2 with w, both with frequency
     // 10000^(-2 (j mod hd/4) / (hd/2))  (modeling_qwen2_5_vl.py:129-141, 441-446); slots past hd/2 hold zeros.
     {
@@ -170,9 +174,9 @@ extern "C" int vg_vision_create(vg_model_t m, const vg_vision_config_t* cfg) {
     struct { DevBuf* b; size_t bytes; } ws[] = {
         {&v->w_pix, (size_t)c.max_rows * v->PD * 4}, {&v->w_px, R * v->PDp * 2}, {&v->w_x, R * v->Hp * 4},
         {&v->w_xn, std::max(R, NT * m2) * v->Hp * 2},      // also read as [pad256(tokens)][m2 * Hp] by the merger
-        {&v->w_qkv, R * 3 * v->AD * 2}, {&v->w_q, R * v->AD * 2}, {&v->w_k, R * v->AD * 2}, {&v->w_v, R * v->AD * 2},
-        {&v->w_att, R * v->AD * 2}, {&v->w_act, R * v->Ip * 2}, {&v->w_mid, NT * v->MHp * 2}, {&v->w_out, NT * (size_t)m->E * 4},
-        {&v->w_perm, R * 4}, {&v->w_pos, 3 * R * 4}, {&v->w_cuw, (R / m2 + 2) * 4}, {&v->w_cui, (R + 2) * 4}, {&v->w_order, NT * 4}};
+        {&v->w_qkv, R * v->QKVp * 2}, {&v->w_cs, R * 64 * 8},
+        {&v->w_att, R * v->ATp * 2}, {&v->w_act, R * v->Ip * 2}, {&v->w_mid, NT * v->MHp * 2}, {&v->w_out, NT * (size_t)m->E * 4},
+        {&v->w_perm, R * 4}, {&v->w_pos, 2 * R * 4}, {&v->w_cuw, (R / m2 + 2) * 4}, {&v->w_cui, (R + 2) * 4}, {&v->w_order, NT * 4}};
     for (auto& w : ws) {
         int rc = w.b->alloc(w.bytes);
         if (rc != VR_OK) return bail(rc);
@@ -186,7 +190,7 @@ void vision_destroy(vg_model_s* m) {
 
 int vision_load_weight(vg_model_s* m, const std::string& key, const void* src, int bf, const int64_t* shape, int ndim, size_t numel) {
     VisionTower* v = m->vis;
-    const int H = v->H, I = v->I, half = v->half, AD = v->AD;
+    const int H = v->H, I = v->I, half = v->half, hh = v->hh, AD = v->AD;
     auto bad_shape = [&]() { return fail(VR_ERR_INVALID, "unexpected shape for visual.%s", key.c_str()); };
     auto vec = [&](Vec& x, int n, int n_alloc) { if (numel != (size_t)n) return bad_shape(); return load_vec(x, src, bf, n, n_alloc); };
     // a whole [n][k] matrix under row / column block maps, and its bias under the row map
@@ -228,10 +232,10 @@ int vision_load_weight(vg_model_s* m, const std::string& key, const void* src, i
         VisBlock& b = v->blocks[n];
         if (sub == "norm1.weight") return vec(b.n1, H, v->Hp);
         if (sub == "norm2.weight") return vec(b.n2, H, v->Hp);
-        // q | k | v rows of head h, channel c: slot row (part * heads + h) * 128 + (c < half ? c : 64 + c - half)
-        if (sub == "attn.qkv.weight") return mat(b.qkv, 3 * AD, H, 3 * H, H, half, 64, 0, H, H);
-        if (sub == "attn.qkv.bias") return bias(b.qkv, 3 * AD, 3 * H, half, 64, 0);
-        if (sub == "attn.proj.weight") return mat(b.proj, H, AD, H, H, H, H, 0, half, 64);
+        // q | k | v rows of head h, channel c: slot row (part * heads + h) * 2 hh + (c < half ? c : hh + c - half)
+        if (sub == "attn.qkv.weight") return mat(b.qkv, 3 * AD, H, 3 * H, H, half, hh, 0, H, H);
+        if (sub == "attn.qkv.bias") return bias(b.qkv, 3 * AD, 3 * H, half, hh, 0);
+        if (sub == "attn.proj.weight") return mat(b.proj, H, AD, H, H, H, H, 0, half, hh);
         if (sub == "attn.proj.bias") return bias(b.proj, H, H, H, H, 0);
         // 16-row [gate | up] interleave of EPI_SWIGLU, bias likewise
         for (int up = 0; up < 2; ++up) {
@@ -272,10 +276,10 @@ extern "C" int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t
     const int R = p.rows, NT = p.tokens, m2 = v->m2, H = v->H, Hp = v->Hp, AD = v->AD, E = m->E;
     m->vis_tokens = 0;
     // ---- geometry to the device: row permutation, (h, w) of every permuted row, segment boundaries
-    std::vector<int> perm(R), pos(3 * (size_t)v->Rcap, 0);
+    std::vector<int> perm(R), pos(2 * (size_t)R);
     for (int i = 0; i < NT; ++i)
         for (int u = 0; u < m2; ++u) perm[i * m2 + u] = p.order[i] * m2 + u;
-    for (int r = 0; r < R; ++r) { pos[(size_t)v->Rcap + r] = p.hw[2 * perm[r]]; pos[2 * (size_t)v->Rcap + r] = p.hw[2 * perm[r] + 1]; }
+    for (int r = 0; r < R; ++r) { pos[r] = p.hw[2 * perm[r]]; pos[(size_t)R + r] = p.hw[2 * perm[r] + 1]; }
     HIPCHK(hipMemcpyAsync(v->w_perm.p, perm.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(v->w_pos.p, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(v->w_cuw.p, p.win_bounds.data(), p.win_bounds.size() * 4, hipMemcpyHostToDevice, s));
@@ -283,6 +287,7 @@ extern "C" int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t
     HIPCHK(hipMemcpyAsync(v->w_order.p, p.order.data(), (size_t)NT * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(v->w_pix.p, pixels, (size_t)R * v->PD * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));                  // the host vectors above go away with this frame
+    HIPCHK(launch_rope2d_table(v->w_pos.as<int>(), v->w_pos.as<int>() + R, R, v->hd / 4, v->inv_freq.as<float>(), v->w_cs.p, s));
     // ---- patch embedding over the permuted bf16 pixel rows
     HIPCHK(launch_gather_rows_bf16(v->w_pix.as<float>(), v->w_perm.as<int>(), R, v->PD, v->w_px.p, v->PDp, s));
     float* x = v->w_x.as<float>();
@@ -292,20 +297,21 @@ extern "C" int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t
     const int nb = (int)v->blocks.size();
     for (int l = 0; l < nb; ++l) {
         VisBlock& b = v->blocks[l];
-        { GemmArgs a = gen_gemm_args(v->w_xn.p, Hp, b.qkv, R, v->w_qkv.p, 3 * AD); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s)); }
-        HIPCHK(launch_mrope_cache(v->w_qkv.p, nullptr, 0, 0, nullptr, 3 * AD, R, v->heads, v->heads, v->w_pos.as<int>(), v->Rcap, 0,
-                                  v->hd / 4, v->inv_freq.as<float>(), v->w_q.p, AD, v->w_k.p, v->w_v.p, AD, 0, nullptr, s));
+        { GemmArgs a = gen_gemm_args(v->w_xn.p, Hp, b.qkv, R, v->w_qkv.p, v->QKVp); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s)); }
+        HIPCHK(launch_rope2d_inplace(v->w_qkv.p, v->QKVp, R, 2 * v->heads, v->hh, v->w_cs.p, s));
         {
             AttnArgs a{};
-            a.q = v->w_q.p; a.ldq = AD; a.k = v->w_k.p; a.ldk = AD; a.v = v->w_v.p; a.ldv = AD; a.out = v->w_att.p; a.ldo = AD;
+            const char* qkv = (const char*)v->w_qkv.p;
+            a.q = qkv; a.k = qkv + (size_t)AD * 2; a.v = qkv + (size_t)AD * 4; a.ldq = a.ldk = a.ldv = v->QKVp;
+            a.out = v->w_att.p; a.ldo = v->ATp;
             const bool fullatt = v->full[l];
             a.cu_q = a.cu_kv = fullatt ? v->w_cui.as<int>() : v->w_cuw.as<int>();
             a.B = (int)(fullatt ? p.img_bounds.size() : p.win_bounds.size()) - 1;
             a.max_q = fullatt ? p.max_img : p.max_win;
-            a.heads = v->heads; a.head_dim = 128; a.scale = 1.0f / sqrtf((float)v->hd); a.causal = 0; a.q_shared = 0; a.kv_group = 1;
+            a.heads = v->heads; a.head_dim = 2 * v->hh; a.scale = 1.0f / sqrtf((float)v->hd); a.causal = 0; a.q_shared = 0; a.kv_group = 1;
             HIPCHK(launch_attention(a, s));
         }
-        { GemmArgs a = gen_gemm_args(v->w_att.p, AD, b.proj, R, x, Hp); a.resid = x; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
+        { GemmArgs a = gen_gemm_args(v->w_att.p, v->ATp, b.proj, R, x, Hp); a.resid = x; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }
         HIPCHK(launch_rmsnorm(x, R, H, Hp, b.n2.v.as<float>(), eps, v->w_xn.p, Hp, s));
         { GemmArgs a = gen_gemm_args(v->w_xn.p, Hp, b.gu, R, v->w_act.p, v->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
         { GemmArgs a = gen_gemm_args(v->w_act.p, v->Ip, b.down, R, x, Hp); a.resid = x; HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s)); }

@@ -83,6 +83,10 @@ hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_pa
                               int ld, int T, int H, int KV, const int* pos3, int pos_stride, int sec_t, int sec_h,
                               const float* inv_freq, void* q_out, int ldq, void* k_cache, void* v_cache, int ld_cache,
                               int cache_row0, int* cu_kv, hipStream_t s);
+// vision tower: cs f32 [T][64][2] = (cos, sin)((p < sec_h ? pos_h : pos_w)[t] * freq[p]); then q / k head slots (2 * hh
+// wide, pairs (p, p + hh), hh <= 64) of bf16 qkv rows rotated in place, slots [0, n_slots) at columns slot * 2 * hh
+hipError_t launch_rope2d_table(const int* pos_h, const int* pos_w, int T, int sec_h, const float* freq, void* cs, hipStream_t s);
+hipError_t launch_rope2d_inplace(void* qkv, int ld, int T, int n_slots, int hh, const void* cs, hipStream_t s);
 hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hipStream_t s);
 // repetition penalty over the seen ids, temperature sampling (Gumbel-max; 0 = argmax), marks the chosen token seen
 hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
