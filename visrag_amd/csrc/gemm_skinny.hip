@@ -24,6 +24,11 @@ constexpr int SK_W_BYTES = 256 * 128, SK_A_BYTES = 16 * 128;
 constexpr int SK_STAGE = SK_W_BYTES + SK_A_BYTES;
 constexpr int SK_SMEM = SK_STAGES * SK_STAGE;
 constexpr unsigned SK_OOB = 0x80000000u;
+// cache policy of the weight loads: nt (aux bit 1) — every byte of W is read once, by one CU
+#ifndef VR_SKINNY_W_AUX
+#define VR_SKINNY_W_AUX 2
+#endif
+constexpr int SK_W_AUX = VR_SKINNY_W_AUX;
 
 }  // namespace
 
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
         const unsigned kb = kt < nk ? (unsigned)kt * (GEMM_BK * 2) : SK_OOB;
 #pragma unroll
         for (int d = 0; d < 8; ++d)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(st + wave * 8192 + d * 1024), 16, lofW + kb, sW0 + d * rgW, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(st + wave * 8192 + d * 1024), 16, lofW + kb, sW0 + d * rgW, 0, SK_W_AUX);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(st + SK_W_BYTES + (wave & 1) * 1024), 16, lofA + kb, sA0, 0, 0);
     };
     f32x4 acc[4];
