@@ -97,6 +97,20 @@ int vg_sample(vg_model_t m, float temperature, float repetition_penalty, uint64_
               void* stream);
 /* Append one token at position pos[3] (all three equal for generated text) and compute its logits. */
 int vg_decode(vg_model_t m, int32_t token, const int32_t pos[3], void* stream);
+/* Free-running generation: the steps after the first token without a host round trip per token.  After vg_prefill +
+ * vg_sample (whose token stays on the device), vg_run_begin fixes the sampling parameters and the position of the first
+ * appended token; every vg_run_step ENQUEUES one step — append the last sampled token at the next position, compute
+ * its logits, sample the next token with the rules of vg_sample (noise index first_step, first_step + 1, ...) — as one
+ * captured hipGraph launch and returns at once; vg_run_token(i) waits for step i's token (steps are numbered from 0
+ * within the run; at most 8 may be in flight uncollected).  Token, positions and cache length advance on the device.
+ * A caller that stops on an end-of-sequence token simply stops enqueuing (a step already in flight appends one unused
+ * row).  vg_run_end — or any other vg_* call on the model — waits for the steps in flight.
+ * stream NULL = a stream the model owns. */
+int vg_run_begin(vg_model_t m, int32_t position, float temperature, float repetition_penalty, uint64_t seed,
+                 int32_t first_step, void* stream);
+int vg_run_step(vg_model_t m);
+int vg_run_token(vg_model_t m, int32_t index, int32_t* token);
+int vg_run_end(vg_model_t m);
 /* copy the current logits (f32 [vocab]) to the host — tests */
 int vg_logits(vg_model_t m, float* out, void* stream);
 int vg_cache_len(vg_model_t m, int32_t* len);

@@ -153,3 +153,47 @@ def test_sampling_kernel(setup):
     assert len(picks) > 4
     top = set(torch.topk(logits, 200).indices.tolist())
     assert len(picks & top) >= len(picks) - 2          # softmax mass sits on the top logits
+
+
+@pytest.mark.parametrize("temperature", [0.0, 0.7])
+def test_free_running_steps_equal_host_driven_steps(setup, temperature):
+    """generate(pipelined=True) — captured decode + sample steps replayed with token, position and cache length
+    advancing on the device — produces the tokens of the one-call-pair-per-token loop, across the point where the
+    decode attention starts cutting the cache into ranges (128 rows) and with sampling noise."""
+    from visrag_amd.evisrag import SamplingParams
+    g, cfg, w, llm = setup
+    ids, embs, grids = _prompt(g, "b")
+    sp = SamplingParams(temperature=temperature, repetition_penalty=1.05, max_tokens=140, seed=11, stop_token_ids=())
+    pr = [{"prompt_token_ids": ids, "multi_modal_data": {"image_embeds": embs, "image_grids": grids}}]
+    a = llm.generate(pr, sp, pipelined=False)[0].outputs[0].token_ids
+    b = llm.generate(pr, sp, pipelined=True)[0].outputs[0].token_ids
+    assert len(a) == 140 and a == b
+    la = llm.logits()                                             # state after a free run is usable: logits of the last step
+    assert np.isfinite(la).all()
+    # a stop token ends the run early (one step may be in flight); the model is reusable afterwards
+    stop = a[5]
+    c = llm.generate(pr, SamplingParams(temperature=temperature, repetition_penalty=1.05, max_tokens=140, seed=11,
+                                        stop_token_ids=(stop,)), pipelined=True)[0].outputs[0].token_ids
+    assert c == a[:a.index(stop) + 1]
+    assert llm.generate(pr, sp, pipelined=True)[0].outputs[0].token_ids == a
+
+
+def test_run_api_errors(setup):
+    from visrag_amd._lib import VisragHipError
+    g, cfg, w, llm = setup
+    ids, embs, grids = _prompt(g, "a")
+    llm.prefill(ids, embs, grids)
+    with pytest.raises(VisragHipError):
+        llm.run_step()                                            # no run in progress
+    from visrag_amd.evisrag import SamplingParams
+    sp = SamplingParams(temperature=0.0, repetition_penalty=1.0)
+    with pytest.raises(VisragHipError):
+        llm.run_begin(len(ids), sp)                               # no sampled token on the device yet
+    llm.sample(sp, 0)
+    llm.run_begin(len(ids), sp)
+    llm.run_step()
+    with pytest.raises(VisragHipError):
+        llm.run_token(1)                                          # only step 0 has been enqueued
+    t0 = llm.run_token(0)
+    assert 0 <= t0 < cfg.vocab_size
+    llm.run_end()

@@ -93,6 +93,10 @@ GEN_SIGNATURES = {
     "vg_decode": (C.c_int, [_vp, _i32, C.POINTER(_i32), _vp]),
     "vg_logits": (C.c_int, [_vp, _vp, _vp]),
     "vg_cache_len": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "vg_run_begin": (C.c_int, [_vp, _i32, _f32, _f32, C.c_uint64, _i32, _vp]),
+    "vg_run_step": (C.c_int, [_vp]),
+    "vg_run_token": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
+    "vg_run_end": (C.c_int, [_vp]),
     "vg_vision_create": (C.c_int, [_vp, C.POINTER(VGVisionConfig)]),
     "vg_vision_encode": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "vg_vision_plan": (C.c_int, [C.POINTER(VGVisionConfig), _vp, _i32, _vp, _vp, C.POINTER(_i32), _vp]),

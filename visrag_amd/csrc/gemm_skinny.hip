@@ -40,11 +40,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     const int n0 = tn * 256;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int Ks = p.K / ks, nk = Ks / GEMM_BK;
+    // K-steps of this split: ceil(steps / ks) each, the last split takes what is left (ks need not divide the steps)
+    const int nk_all = p.K / GEMM_BK, per = (nk_all + ks - 1) / ks;
+    const int k0 = split * per, nk = max(0, min(per, nk_all - k0));
+    const size_t kof = (size_t)k0 * GEMM_BK;
 
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + ((size_t)n0 * p.ldw + (size_t)split * Ks) * 2), 0,
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + ((size_t)n0 * p.ldw + kof) * 2), 0,
                                                          0x7FFFFFFF, 0x00020000);
-    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (size_t)split * Ks * 2), 0, 0x7FFFFFFF, 0x00020000);
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + kof * 2), 0, 0x7FFFFFFF, 0x00020000);
     const unsigned lchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
     const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
     const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
@@ -93,11 +96,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     }
 }
 
-// fp32 planes out[split][M][ldo]; M <= 16 (A and W rows readable up to 16 / the next multiple of 256), K % (ksplit * 64) == 0
+// fp32 planes out[split][M][ldo]; M <= 16 (A and W rows readable up to 16 / the next multiple of 256), K % 64 == 0; split s
+// covers K-steps [s * ceil(steps / ksplit), ...) — a split past the end writes a plane of zeros (+ bias for split 0)
 hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     if (a.M <= 0) return hipSuccess;
-    if (a.M > 16 || a.N % 4 || a.K % (ks * GEMM_BK) || a.rowmap || a.rowbias) return hipErrorInvalidValue;
+    if (a.M > 16 || a.N % 4 || a.K % GEMM_BK || a.rowmap || a.rowbias) return hipErrorInvalidValue;
     const size_t tn = (a.N + 255) / 256;
     if (tn * 256 * (size_t)a.ldw * 2 >= (1ull << 31) || 16 * (size_t)a.lda * 2 >= (1ull << 31)) return hipErrorInvalidValue;
     static unsigned long long attr = 0;     // bit d: set on device d

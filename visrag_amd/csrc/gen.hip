@@ -13,19 +13,34 @@
 //     the residual-adding RMSNorm for o / down).  ~14 GB of bf16 weights per token at 7B: the HBM sets the floor.
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "gen_model.h"
 
-// decode (gemm_skinny.hip): split K so that (256-column tiles) x splits gives the chip about two workgroups per CU
-// to pull on; every split keeps >= 4 K-steps
-static int choose_ksplit(int n, int k) {
+static int end_run(vg_model_s* m);      // waits for the steps of a free run (vg_run_*) still in flight
+
+// decode (gemm_skinny.hip): how many K ranges a GEMM's 256-column tiles are cut into.  One workgroup fits on a CU (its
+// four LDS stages), so the fastest shape is ONE balanced round of workgroups with K loops as long as that allows —
+// measured on the 7B layer (ms per token): gate/up 148 tiles as 148 x 56 K-steps 3.74, 296 x 28 (a second round of 40)
+// 3.94, 592 x 14 3.80; down 14 tiles as 252 x 17 3.74, 112 x 37 3.94, 518 x 8 4.08.  The splits need not divide the
+// K-steps (the last range is shorter); every range keeps >= 4 steps; more tiles than CUs: no split.
+#ifndef VR_KS_QKV
+#define VR_KS_QKV 0
+#define VR_KS_O 0
+#define VR_KS_GU 0
+#define VR_KS_DOWN 0
+#endif
+static int choose_ksplit(int n, int k, int forced = 0) {
+    if (forced > 0) return forced;
     const int tiles = (n + 255) / 256, nk = k / 64;
     int best = 1;
-    for (int d = 2; d <= GEN_KS_MAX && d <= nk / 4; ++d)
-        if (nk % d == 0 && tiles * d <= 512) best = d;
+    for (int d = 2; d <= GEN_KS_MAX && tiles * d <= 256; ++d) {
+        const int per = (nk + d - 1) / d;
+        if (per >= 4 && (d - 1) * per < nk) best = d;
+    }
     return best;
 }
 
@@ -65,9 +80,10 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
         {&m->w_h, T * E * 4}, {&m->w_xn, T * E * 2}, {&m->w_qkv, T * m->QKV * 2}, {&m->w_q, T * m->QD * 2},
         {&m->w_att, T * m->QD * 2}, {&m->w_act, T * (size_t)pad128(m->I) * 2}, {&m->w_last, 256 * E * 2},
         {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(std::max<size_t>(m->QKV, E), (size_t)pad128(2 * m->I)) * 4}, {&m->w_logits, (size_t)m->V * 4},
-        {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, (2 * GEN_ATT_SPLITS + 2) * 4},
+        {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, 4 * 4},
         {&m->w_attp, (size_t)GEN_ATT_SPLITS * m->QD * 2}, {&m->w_lse, (size_t)GEN_ATT_SPLITS * m->H * 4}, {&m->w_seen, (size_t)(m->V + 31) / 32 * 4},
-        {&m->w_tok, 16 + 64 * 8}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4}};
+        {&m->w_tok, 16 + 64 * 8}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4},
+        {&m->w_state, sizeof(GenState)}};
     for (auto& w : ws)
         if ((rc = w.b->alloc(w.bytes)) != VR_OK) return bail(rc);
     return VR_OK;
@@ -76,6 +92,13 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
 extern "C" int vg_destroy(vg_model_t m) {
     if (!m) return VR_OK;
     (void)hipSetDevice(m->device);
+    if (m->run_stream) (void)hipStreamSynchronize(m->run_stream);
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    for (auto& e : m->run_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (m->h_tokens) (void)hipHostFree(m->h_tokens);
+    if (m->run_stream) (void)hipStreamDestroy(m->run_stream);
     vision_destroy(m);
     delete m;                           // DevBuf destructors release everything
     return VR_OK;
@@ -171,12 +194,13 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
     if (decode) {
         GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, T, part, QKV);
         a.bias = nullptr;
-        a.ksplit = choose_ksplit(QKV, E);
+        a.ksplit = choose_ksplit(QKV, E, VR_KS_QKV);
         a.split_stride = (size_t)QKV * T;
         HIPCHK(launch_gemm_skinny(a, s));
-        HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV * T, L.qkv.b.as<float>(), QKV, T, m->H, m->KV, m->w_pos.as<int>(),
-                                  m->Tcap, c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD,
-                                  m->kc[l].p, m->vc[l].p, m->KVD, m->len, nullptr, s));
+        GenState* st = m->w_state.as<GenState>();          // position and cache row of the step: on the device
+        HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV * T, L.qkv.b.as<float>(), QKV, T, m->H, m->KV, st->pos,
+                                  1, c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD,
+                                  m->kc[l].p, m->vc[l].p, m->KVD, 0, nullptr, s, &st->len));
     } else {
         GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, T, m->w_qkv.p, QKV);
         HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s));
@@ -185,29 +209,31 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
                                   m->vc[l].p, m->KVD, m->len, nullptr, s));
     }
     // ---- grouped-query attention over the cache.  Prefill: causal within the prompt.  Decode: the new row sees the
-    //      whole cache; one query row x 28 heads would be 28 workgroups, so the cache is cut into dec_splits ranges
-    //      that run as independent "sequences" sharing the query row (q_shared), and a small kernel merges them by
-    //      their log-sum-exps.
+    //      whole cache; one query row x 28 heads would be 28 workgroups, so the cache is cut into KV ranges
+    //      (decode_begin_kernel, GenState::cu_kv) that run as independent "sequences" sharing the query row (q_shared) —
+    //      always GEN_ATT_SPLITS of them on the grid, the ones past the end empty — and a small kernel merges the
+    //      GenState::splits real ones by their log-sum-exps.  Nothing here depends on a host-side length.
     {
-        int* cu_kv = cu + GEN_ATT_SPLITS + 1;
         AttnArgs a{};
         a.q = m->w_q.p; a.ldq = QD; a.k = m->kc[l].p; a.ldk = m->KVD; a.v = m->vc[l].p; a.ldv = m->KVD;
-        a.cu_q = cu; a.cu_kv = cu_kv;
         a.heads = m->H; a.head_dim = 128; a.scale = 1.0f / sqrtf(128.0f); a.kv_group = m->H / m->KV;
-        if (decode && m->dec_splits > 1) {
-            a.out = m->w_attp.p; a.ldo = QD; a.B = m->dec_splits; a.max_q = 1; a.causal = 0; a.q_shared = 1;
+        if (decode) {
+            GenState* st = m->w_state.as<GenState>();
+            a.cu_q = st->cu_q; a.cu_kv = st->cu_kv;
+            a.out = m->w_attp.p; a.ldo = QD; a.B = GEN_ATT_SPLITS; a.max_q = 1; a.causal = 0; a.q_shared = 1;
             a.lse = m->w_lse.as<float>();
             HIPCHK(launch_attention(a, s));
-            HIPCHK(launch_attn_combine(m->w_attp.p, QD, m->w_lse.as<float>(), m->dec_splits, m->H, m->w_att.p, s));
+            HIPCHK(launch_attn_combine(m->w_attp.p, QD, m->w_lse.as<float>(), 0, m->H, m->w_att.p, s, &st->splits));
         } else {
-            a.out = m->w_att.p; a.ldo = QD; a.B = 1; a.max_q = T; a.causal = decode ? 0 : 1; a.q_shared = 0;
+            a.cu_q = cu; a.cu_kv = cu + 2;
+            a.out = m->w_att.p; a.ldo = QD; a.B = 1; a.max_q = T; a.causal = 1; a.q_shared = 0;
             HIPCHK(launch_attention(a, s));
         }
     }
     // ---- o projection + residual, post-attention norm
     if (decode) {
         GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, T, part, E);
-        a.ksplit = choose_ksplit(E, QD);
+        a.ksplit = choose_ksplit(E, QD, VR_KS_O);
         a.split_stride = (size_t)E * T;
         HIPCHK(launch_gemm_skinny(a, s));
         HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E * T, E, 1.0f, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
@@ -221,12 +247,12 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
     if (decode) {
         const int N2 = L.gu.n_pad;
         GemmArgs g = gen_gemm_args(m->w_xn.p, E, L.gu, T, part, N2);
-        g.ksplit = choose_ksplit(N2, E);
+        g.ksplit = choose_ksplit(N2, E, VR_KS_GU);
         g.split_stride = (size_t)N2 * T;
         HIPCHK(launch_gemm_skinny(g, s));
         HIPCHK(launch_swiglu_sum(part, g.ksplit, (size_t)N2 * T, N2, T, m->I, m->w_act.p, Ip, s));
         GemmArgs a = gen_gemm_args(m->w_act.p, Ip, L.down, T, part, E);
-        a.ksplit = choose_ksplit(E, L.down.k_pad);
+        a.ksplit = choose_ksplit(E, L.down.k_pad, VR_KS_DOWN);
         a.split_stride = (size_t)E * T;
         HIPCHK(launch_gemm_skinny(a, s));
         HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E * T, E, 1.0f, next_norm, c.rms_norm_eps, m->w_xn.p, E, s));
@@ -267,17 +293,17 @@ extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int
     for (int i = 0; i < n_embed; ++i)
         if (embed_rows[i] < 0 || embed_rows[i] >= T) return fail(VR_ERR_INVALID, "embedding row %d out of range", embed_rows[i]);
     VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
     hipStream_t s = (hipStream_t)stream;
     const int E = m->E;
     m->len = 0;
     m->have_logits = false;
+    m->tok_on_device = false;
     HIPCHK(hipMemsetAsync(m->w_seen.p, 0, m->w_seen.bytes, s));
     HIPCHK(hipMemcpyAsync(m->w_ids.p, ids, (size_t)T * 4, hipMemcpyHostToDevice, s));
     for (int c = 0; c < 3; ++c)
         HIPCHK(hipMemcpyAsync(m->w_pos.as<int>() + (size_t)c * m->Tcap, pos3 + (size_t)c * T, (size_t)T * 4, hipMemcpyHostToDevice, s));
-    int cu_host[2 * GEN_ATT_SPLITS + 2] = {0};
-    cu_host[1] = T;                                   // cu_q = {0, T}
-    cu_host[GEN_ATT_SPLITS + 2] = T;                  // cu_kv = {0, T}
+    const int cu_host[4] = {0, T, 0, T};              // cu_q, cu_kv
     HIPCHK(hipMemcpyAsync(m->w_cu.p, cu_host, sizeof(cu_host), hipMemcpyHostToDevice, s));
     HIPCHK(launch_mark_seen(m->w_ids.as<int>(), T, m->w_seen.as<unsigned>(), m->V, s));
     HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
@@ -298,35 +324,47 @@ extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int
     return gen_head(m, m->w_h.as<float>() + (size_t)(T - 1) * E, false, s);
 }
 
+// One decode step on stream s: everything it needs beyond the weights and caches is in GenState on the device, so the
+// same sequence of launches serves a host-driven step (vg_decode uploads token / positions / length first) and the
+// captured graph of a free-running step (sampled: + the sampling kernels, which also advance the state).
+static int enqueue_decode(vg_model_s* m, hipStream_t s, bool sampled, float temperature, float penalty, unsigned long long seed) {
+    const int E = m->E;
+    GenState* st = m->w_state.as<GenState>();
+    HIPCHK(launch_decode_begin(st, s));
+    HIPCHK(launch_embed_gather(&st->token, 1, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
+    HIPCHK(launch_rmsnorm(m->w_h.as<float>(), 1, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
+    const int nl = (int)m->layers.size();
+    for (int l = 0; l < nl; ++l)
+        VRCHK(gen_layer(m, l, 1, true, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : m->final_norm.v.as<float>(), s));
+    VRCHK(gen_head(m, nullptr, true, s));
+    if (sampled)
+        HIPCHK(launch_sample(m->w_logits.as<float>(), m->V, m->w_seen.as<unsigned>(), penalty, temperature, seed, 0, m->w_tok.as<int>(),
+                             m->w_tok.as<unsigned long long>() + 2, s, st, 1, 1));
+    return VR_OK;
+}
+
+// a free run still has steps in flight: finish them before anything else touches the model
+static int end_run(vg_model_s* m) {
+    if (!m->running) return VR_OK;
+    m->running = false;
+    HIPCHK(hipStreamSynchronize(m->run_on));
+    return VR_OK;
+}
+
 extern "C" int vg_decode(vg_model_t m, int32_t token, const int32_t pos[3], void* stream) {
     if (!m || !pos) return fail(VR_ERR_INVALID, "NULL argument");
     if (!m->finalized || m->len <= 0) return fail(VR_ERR_STATE, "no sequence in progress (vg_prefill first)");
     if (m->len >= m->c.max_len) return fail(VR_ERR_CAPACITY, "KV cache is full (%d rows)", m->c.max_len);
     if (token < 0 || token >= m->V) return fail(VR_ERR_INVALID, "token id %d out of range", token);
     VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
     hipStream_t s = (hipStream_t)stream;
-    const int E = m->E;
-    // one token: id, its three positions and cu_q = {0, 1} travel as one small pinned-free copy each (a few bytes)
-    // KV ranges of this step's attention: multiples of the kernel's 64-key tile, enough of them for ~8 workgroups per head
-    const int L = m->len + 1;
-    int splits = std::min(GEN_ATT_SPLITS, std::max(1, (L + 127) / 128));
-    const int chunk = ((L + splits - 1) / splits + 63) / 64 * 64;
-    splits = (L + chunk - 1) / chunk;
-    m->dec_splits = splits;
-    int cu_host[2 * GEN_ATT_SPLITS + 2] = {0};
-    for (int i = 0; i <= splits; ++i) { cu_host[i] = splits > 1 ? i : std::min(i, 1); cu_host[GEN_ATT_SPLITS + 1 + i] = std::min(L, i * chunk); }
-    if (splits == 1) { cu_host[1] = 1; cu_host[GEN_ATT_SPLITS + 2] = L; }
-    HIPCHK(hipMemcpyAsync(m->w_ids.p, &token, 4, hipMemcpyHostToDevice, s));
-    for (int c = 0; c < 3; ++c)
-        HIPCHK(hipMemcpyAsync(m->w_pos.as<int>() + (size_t)c * m->Tcap, pos + c, 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(m->w_cu.p, cu_host, sizeof(cu_host), hipMemcpyHostToDevice, s));
-    HIPCHK(launch_embed_gather(m->w_ids.as<int>(), 1, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
-    HIPCHK(launch_rmsnorm(m->w_h.as<float>(), 1, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
-    const int nl = (int)m->layers.size();
-    for (int l = 0; l < nl; ++l)
-        VRCHK(gen_layer(m, l, 1, true, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : m->final_norm.v.as<float>(), s));
+    const int head[5] = {token, pos[0], pos[1], pos[2], m->len};         // GenState::token, pos[3], len
+    HIPCHK(hipMemcpyAsync(m->w_state.p, head, sizeof(head), hipMemcpyHostToDevice, s));
+    m->tok_on_device = false;
+    VRCHK(enqueue_decode(m, s, false, 0.f, 1.f, 0));
     m->len += 1;
-    return gen_head(m, nullptr, true, s);
+    return VR_OK;
 }
 
 extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penalty, uint64_t seed, int32_t step,
@@ -335,18 +373,93 @@ extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penal
     if (!m->have_logits) return fail(VR_ERR_STATE, "no logits yet (vg_prefill / vg_decode first)");
     if (!(repetition_penalty > 0.f) || temperature < 0.f) return fail(VR_ERR_INVALID, "bad sampling parameters");
     VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(launch_sample(m->w_logits.as<float>(), m->V, m->w_seen.as<unsigned>(), repetition_penalty, temperature, seed,
-                         (unsigned)step, m->w_tok.as<int>(), m->w_tok.as<unsigned long long>() + 2, s));
+                         (unsigned)step, m->w_tok.as<int>(), m->w_tok.as<unsigned long long>() + 2, s, m->w_state.as<GenState>(), 0, 0));
     HIPCHK(hipMemcpyAsync(token_out, m->w_tok.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    m->tok_on_device = true;
     return VR_OK;
+}
+
+// ---- free-running generation ------------------------------------------------------------------------------------
+static int capture_step(vg_model_s* m, float temperature, float penalty, unsigned long long seed) {
+    if (m->graph_exec && m->g_temp == temperature && m->g_pen == penalty && m->g_seed == seed) return VR_OK;
+    if (m->graph_exec) { HIPCHK(hipGraphExecDestroy(m->graph_exec)); m->graph_exec = nullptr; }
+    if (m->graph) { HIPCHK(hipGraphDestroy(m->graph)); m->graph = nullptr; }
+    HIPCHK(hipStreamBeginCapture(m->run_stream, hipStreamCaptureModeRelaxed));
+    const int rc = enqueue_decode(m, m->run_stream, true, temperature, penalty, seed);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(m->run_stream, &g);       // (always: the stream must leave capture mode)
+    if (rc != VR_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) return fail(VR_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    m->graph = g;
+    HIPCHK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+    m->g_temp = temperature; m->g_pen = penalty; m->g_seed = seed;
+    return VR_OK;
+}
+
+extern "C" int vg_run_begin(vg_model_t m, int32_t position, float temperature, float repetition_penalty, uint64_t seed,
+                            int32_t first_step, void* stream) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    if (!m->finalized || m->len <= 0) return fail(VR_ERR_STATE, "no sequence in progress (vg_prefill first)");
+    if (!m->tok_on_device) return fail(VR_ERR_STATE, "no sampled token on the device (vg_sample first)");
+    if (!(repetition_penalty > 0.f) || temperature < 0.f) return fail(VR_ERR_INVALID, "bad sampling parameters");
+    VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
+    if (!m->run_stream) {
+        HIPCHK(hipStreamCreate(&m->run_stream));        // blocking: ordered against the default stream like any other
+        HIPCHK(hipHostMalloc((void**)&m->h_tokens, GEN_RUN_RING * sizeof(int), hipHostMallocDefault));
+        for (auto& e : m->run_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : m->run_stream;
+    HIPCHK(hipStreamSynchronize(s));
+    VRCHK(capture_step(m, temperature, repetition_penalty, seed));
+    const int body[5] = {position, position, position, m->len, first_step};          // GenState::pos[3], len, step
+    HIPCHK(hipMemcpyAsync((char*)m->w_state.p + offsetof(GenState, pos), body, sizeof(body), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    m->running = true; m->run_on = s; m->run_steps = 0;
+    return VR_OK;
+}
+
+extern "C" int vg_run_step(vg_model_t m) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    if (!m->running) return fail(VR_ERR_STATE, "no free run in progress (vg_run_begin)");
+    if (m->len >= m->c.max_len) return fail(VR_ERR_CAPACITY, "KV cache is full (%d rows)", m->c.max_len);
+    VRCHK(set_dev(m->device));
+    const int slot = m->run_steps % GEN_RUN_RING;
+    if (m->run_steps >= GEN_RUN_RING) HIPCHK(hipEventSynchronize(m->run_ev[slot]));     // the slot's previous token has landed
+    HIPCHK(hipGraphLaunch(m->graph_exec, m->run_on));
+    HIPCHK(hipMemcpyAsync(m->h_tokens + slot, m->w_tok.p, 4, hipMemcpyDeviceToHost, m->run_on));
+    HIPCHK(hipEventRecord(m->run_ev[slot], m->run_on));
+    m->len += 1;
+    m->run_steps += 1;
+    m->have_logits = true;
+    return VR_OK;
+}
+
+extern "C" int vg_run_token(vg_model_t m, int32_t index, int32_t* token) {
+    if (!m || !token) return fail(VR_ERR_INVALID, "NULL argument");
+    if (index < 0 || index >= m->run_steps || index < m->run_steps - GEN_RUN_RING)
+        return fail(VR_ERR_INVALID, "step %d is not among the last %d of %d enqueued", index, GEN_RUN_RING, m->run_steps);
+    VRCHK(set_dev(m->device));
+    HIPCHK(hipEventSynchronize(m->run_ev[index % GEN_RUN_RING]));
+    *token = m->h_tokens[index % GEN_RUN_RING];
+    return VR_OK;
+}
+
+extern "C" int vg_run_end(vg_model_t m) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    VRCHK(set_dev(m->device));
+    return end_run(m);
 }
 
 extern "C" int vg_logits(vg_model_t m, float* out, void* stream) {
     if (!m || !out) return fail(VR_ERR_INVALID, "NULL argument");
     if (!m->have_logits) return fail(VR_ERR_STATE, "no logits yet");
     VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
     HIPCHK(hipMemcpyAsync(out, m->w_logits.p, (size_t)m->V * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VR_OK;

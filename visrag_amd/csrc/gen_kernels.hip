@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restri
                                                           int pos_stride, int sec_t, int sec_h, const float* __restrict__ inv_freq,
                                                           bf16_t* __restrict__ q_out, int ldq, bf16_t* __restrict__ k_cache,
                                                           bf16_t* __restrict__ v_cache, int ld_cache, int cache_row0,
-                                                          int* __restrict__ cu_kv) {
+                                                          int* __restrict__ cu_kv, const int* __restrict__ row0_dev) {
+    if (row0_dev) cache_row0 = *row0_dev;              // decode steps: the cache length lives on the device (GenState::len)
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int slots = H + 2 * KV;
@@ -75,12 +76,12 @@ __global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restri
 hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_parts, size_t plane_stride, const float* bias,
                               int ld, int T, int H, int KV, const int* pos3, int pos_stride, int sec_t, int sec_h,
                               const float* inv_freq, void* q_out, int ldq, void* k_cache, void* v_cache, int ld_cache,
-                              int cache_row0, int* cu_kv, hipStream_t s) {
+                              int cache_row0, int* cu_kv, hipStream_t s, const int* row0_dev) {
     if (T <= 0) return hipSuccess;
     const int slots = T * (H + 2 * KV);
     hipLaunchKernelGGL(mrope_cache_kernel, dim3((slots + 3) / 4), dim3(256), 0, s, (const bf16_t*)src_bf16, parts, n_parts,
                        plane_stride, bias, ld, T, H, KV, pos3, pos_stride, sec_t, sec_h, inv_freq, (bf16_t*)q_out, ldq,
-                       (bf16_t*)k_cache, (bf16_t*)v_cache, ld_cache, cache_row0, cu_kv);
+                       (bf16_t*)k_cache, (bf16_t*)v_cache, ld_cache, cache_row0, cu_kv, row0_dev);
     return hipGetLastError();
 }
 
@@ -155,8 +156,9 @@ __device__ __forceinline__ unsigned long long sample_key(float l, bool seen, flo
 __global__ __launch_bounds__(256) void sample_partial_kernel(const float* __restrict__ logits, int vocab,
                                                              const unsigned* __restrict__ seen, float penalty, float temperature,
                                                              unsigned long long seed, unsigned step,
-                                                             unsigned long long* __restrict__ part) {
+                                                             unsigned long long* __restrict__ part, const GenState* __restrict__ st) {
     __shared__ unsigned long long best[4];
+    if (st) step = (unsigned)st->step;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float inv_t = temperature > 0.f ? 1.0f / temperature : 1.0f;
     unsigned long long key = 0ull;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(64) void sample_final_kernel(const unsigned long long* __restrict__ part, unsigned* __restrict__ seen,
-                                                          int* __restrict__ token_out) {
+                                                          int* __restrict__ token_out, GenState* __restrict__ st, int advance) {
     unsigned long long key = part[threadIdx.x];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -191,16 +193,42 @@ __global__ __launch_bounds__(64) void sample_final_kernel(const unsigned long lo
         const int tok = (int)(~(unsigned)(key & 0xFFFFFFFFull));
         *token_out = tok;
         seen[tok >> 5] |= 1u << (tok & 31);
+        if (st) {
+            st->token = tok;                       // the next decode step may take it from here (no host round trip)
+            if (advance) {                         // free-running generation: this step's row is in the cache, move on
+                st->len += 1; st->step += 1;
+                st->pos[0] += 1; st->pos[1] += 1; st->pos[2] += 1;
+            }
+        }
     }
 }
 
 // `scratch`: SAMPLE_WGS 64-bit words on the device
 hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
-                         unsigned long long seed, unsigned step, int* token_out, unsigned long long* scratch, hipStream_t s) {
+                         unsigned long long seed, unsigned step, int* token_out, unsigned long long* scratch, hipStream_t s,
+                         GenState* st, int step_from_state, int advance) {
     static_assert(SAMPLE_WGS == 64, "the final reduction is one wave");
     hipLaunchKernelGGL(sample_partial_kernel, dim3(SAMPLE_WGS), dim3(256), 0, s, logits, vocab, (const unsigned*)seen, penalty,
-                       temperature, seed, step, scratch);
-    hipLaunchKernelGGL(sample_final_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)scratch, seen, token_out);
+                       temperature, seed, step, scratch, (const GenState*)(step_from_state ? st : nullptr));
+    hipLaunchKernelGGL(sample_final_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)scratch, seen, token_out, st, advance);
+    return hipGetLastError();
+}
+
+// Start of a decode step: the KV ranges of its attention from the cache length on the device.  One new row sees the
+// whole cache (len + 1 rows); one query row x 28 heads would be 28 workgroups, so the cache is cut into up to
+// GEN_ATT_SPLITS ranges (multiples of the attention kernel's 64-key tile, ~128 keys or more each) that run as
+// independent "sequences" sharing the query row; ranges past the end are empty (the attention kernel skips them).
+__global__ void decode_begin_kernel(GenState* __restrict__ st) {
+    if (threadIdx.x != 0) return;
+    const int L = st->len + 1;
+    int splits = min(GEN_ATT_SPLITS, max(1, (L + 127) / 128));
+    const int chunk = ((L + splits - 1) / splits + 63) / 64 * 64;
+    splits = (L + chunk - 1) / chunk;
+    st->splits = splits;
+    for (int i = 0; i <= GEN_ATT_SPLITS; ++i) { st->cu_q[i] = i; st->cu_kv[i] = min(L, i * chunk); }
+}
+hipError_t launch_decode_begin(GenState* st, hipStream_t s) {
+    hipLaunchKernelGGL(decode_begin_kernel, dim3(1), dim3(64), 0, s, st);
     return hipGetLastError();
 }
 
@@ -232,7 +260,8 @@ hipError_t launch_gather_rows_bf16(const float* src, const int* row_idx, int n, 
 
 // one decode step's attention was run as S independent KV ranges (attention_kernel with q_shared): merge them
 __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, const float* __restrict__ lse, int S, int heads,
-                                    bf16_t* __restrict__ out) {
+                                    bf16_t* __restrict__ out, const int* __restrict__ S_dev) {
+    if (S_dev) S = *S_dev;
     const int h = blockIdx.x, d = threadIdx.x;        // 128 threads: one per channel of the head
     float mx = -INFINITY;
     for (int s = 0; s < S; ++s) mx = fmaxf(mx, lse[s * heads + h]);
@@ -244,8 +273,9 @@ __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, co
     }
     out[h * 128 + d] = f2bf(num / den);
 }
-hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s) {
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(heads), dim3(128), 0, s, (const bf16_t*)part, ldp, lse, S, heads, (bf16_t*)out);
+hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s,
+                               const int* S_dev) {
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(heads), dim3(128), 0, s, (const bf16_t*)part, ldp, lse, S, heads, (bf16_t*)out, S_dev);
     return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ struct GenLayer {
 };
 
 constexpr int GEN_KS_MAX = 64;      // split-K planes of the decode path
-constexpr int GEN_ATT_SPLITS = 16;  // most KV ranges one decode step's attention is cut into
+constexpr int GEN_RUN_RING = 8;     // most free-running steps in flight before their tokens are collected
 
 struct VisionTower;                 // gen_vision.hip
 
@@ -34,7 +34,19 @@ struct vg_model_s {
     int Tcap = 0;
     DevBuf w_h, w_xn, w_qkv, w_q, w_att, w_act, w_last, w_part, w_logits, w_ids, w_pos, w_cu, w_seen, w_tok, w_erows, w_emb;
     DevBuf w_attp, w_lse;               // decode: partial attention rows [GEN_ATT_SPLITS][QD] bf16 + their log-sum-exps
-    int dec_splits = 1;                 // KV ranges of the current decode step (w_cu: cu_q at [0..], cu_kv at [GEN_ATT_SPLITS + 1..])
+    DevBuf w_state;                     // GenState: token / positions / cache length / KV ranges of the decode step, on the device
+    bool tok_on_device = false;         // w_state.token holds the last sampled token (vg_sample / a free-running step)
+    // free-running generation (vg_run_*): one decode + sample step captured as a hipGraph, replayed per token
+    hipStream_t run_stream = nullptr;   // capture stream; also the stream of a run when the caller passes none
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    float g_temp = -1.f, g_pen = -1.f;  // sampling parameters baked into the captured step
+    unsigned long long g_seed = 0;
+    bool running = false;
+    hipStream_t run_on = nullptr;       // stream of the current run
+    int run_steps = 0;                  // steps enqueued in the current run
+    int* h_tokens = nullptr;            // pinned ring [GEN_RUN_RING] the sampled tokens are copied into
+    hipEvent_t run_ev[8] = {};          // run_ev[i % 8]: step i's token has landed
     VisionTower* vis = nullptr;         // attached by vg_vision_create
     int vis_tokens = 0;                 // embedding rows the last vg_vision_encode left in w_emb (image-token order)
 };

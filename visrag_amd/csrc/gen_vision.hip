@@ -266,6 +266,7 @@ extern "C" int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t
     if (!m || !pixels || !grid_thw) return fail(VR_ERR_INVALID, "NULL argument");
     if (!m->vis) return fail(VR_ERR_STATE, "no vision tower (vg_vision_create)");
     if (!m->finalized) return fail(VR_ERR_STATE, "vg_finalize has not succeeded");
+    if (m->running) return fail(VR_ERR_STATE, "a free run is in progress (vg_run_end first)");
     if (n_images <= 0) return fail(VR_ERR_INVALID, "no images");
     VisionTower* v = m->vis;
     VisPlan p;

@@ -76,27 +76,44 @@ struct AttnArgs {
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
 // ---- EVisRAG generator (gen_kernels.hip) ---------------------------------------------------
+constexpr int GEN_ATT_SPLITS = 16;  // most KV ranges one decode step's attention is cut into
+// What a decode step needs beyond the caches, resident on the device so that consecutive steps need no host round trip
+// (gen.hip: host-driven steps upload the first five words; free-running steps advance them on the device).
+struct GenState {
+    int token;                      // the token this step appends
+    int pos[3];                     // its temporal / height / width position
+    int len;                        // KV-cache rows in use before this step
+    int step;                       // index of the next sampled token (selects the sampling noise)
+    int splits;                     // KV ranges of this step's attention (decode_begin_kernel)
+    int pad;
+    int cu_q[GEN_ATT_SPLITS + 1], cu_kv[GEN_ATT_SPLITS + 1];
+};
+hipError_t launch_decode_begin(GenState* st, hipStream_t s);
 // multimodal RoPE on q (in place into q_out) and k (into the K cache at rows cache_row0 + t), v copied into the V
 // cache; head_dim 128; pos3 = [3][pos_stride] ints (temporal, height, width); inv_freq f32 [64]; source = bf16 qkv rows
 // or (parts != null) fp32 split-K planes + bias; cu_kv (optional) receives {0, cache_row0 + T}
 hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_parts, size_t plane_stride, const float* bias,
                               int ld, int T, int H, int KV, const int* pos3, int pos_stride, int sec_t, int sec_h,
                               const float* inv_freq, void* q_out, int ldq, void* k_cache, void* v_cache, int ld_cache,
-                              int cache_row0, int* cu_kv, hipStream_t s);
+                              int cache_row0, int* cu_kv, hipStream_t s, const int* row0_dev = nullptr);   // row0_dev: cache_row0 read on the device
 // vision tower: cs f32 [T][64][2] = (cos, sin)((p < sec_h ? pos_h : pos_w)[t] * freq[p]); then q / k head slots (2 * hh
 // wide, pairs (p, p + hh), hh <= 64) of bf16 qkv rows rotated in place, slots [0, n_slots) at columns slot * 2 * hh
 hipError_t launch_rope2d_table(const int* pos_h, const int* pos_w, int T, int sec_h, const float* freq, void* cs, hipStream_t s);
 hipError_t launch_rope2d_inplace(void* qkv, int ld, int T, int n_slots, int hh, const void* cs, hipStream_t s);
 hipError_t launch_mark_seen(const int* ids, int n, unsigned* seen, int vocab, hipStream_t s);
-// repetition penalty over the seen ids, temperature sampling (Gumbel-max; 0 = argmax), marks the chosen token seen
+// repetition penalty over the seen ids, temperature sampling (Gumbel-max; 0 = argmax), marks the chosen token seen.
+// st (optional): the token also goes to st->token; step_from_state: the noise index is st->step; advance: the step's
+// bookkeeping (len, step, positions + 1) happens here, on the device
 hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float penalty, float temperature,
-                         unsigned long long seed, unsigned step, int* token_out, unsigned long long* scratch64, hipStream_t s);
+                         unsigned long long seed, unsigned step, int* token_out, unsigned long long* scratch64, hipStream_t s,
+                         GenState* st = nullptr, int step_from_state = 0, int advance = 0);
 hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int dim, float* dst, int ld, hipStream_t s);
 // dst[i][:] = bf16(src[row_idx[i]][0..dim)), zero up to ld (src rows are dense: stride dim)
 hipError_t launch_gather_rows_bf16(const float* src, const int* row_idx, int n, int dim, void* dst, int ld, hipStream_t s);
 // out[h*128 + d] = sum_s 2^(lse[s][h] - max) * part[s][h*128 + d] / sum_s 2^(lse[s][h] - max): merges the S partial
 // attention rows (bf16 [S][ldp], each normalised over its own KV range) of one decode step
-hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s);
+hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s,
+                               const int* S_dev = nullptr);      // S_dev: S read on the device
 
 // ---- elementwise / gather / pooling (misc.hip) ---------------------------------------------
 // Fused ToTensor/Normalize + patch-embed conv (patch_embed.hip): g carries the PERMUTED weight (k = ky*3P + kx*3 + c),

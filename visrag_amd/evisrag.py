@@ -204,11 +204,18 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
         tok = llm.sample(sp, 0)
         torch.cuda.synchronize(device); b = time.perf_counter()
         nxt = int(pos3.max()) + 1
-        for step in range(1, answer_tokens):
-            llm.decode(tok, nxt); nxt += 1
-            tok = llm.sample(sp, step)
+        llm._continue(tok, nxt, answer_tokens, sp, (), True)          # captured steps, one enqueued ahead
         torch.cuda.synchronize(device); c = time.perf_counter()
         pre.append(b - a); dec.append((c - b) / max(1, answer_tokens - 1)); tot.append(c - a)
+    # the same steps driven from the host (one vg_decode + vg_sample pair per token): what the capture saves
+    if vision:
+        pos3, _ = llm.prefill_images(ids, px, thw)
+    else:
+        pos3 = llm.prefill(ids, embs, [grid] * n_images)
+    tok = llm.sample(sp, 0)
+    torch.cuda.synchronize(device); b = time.perf_counter()
+    llm._continue(tok, int(pos3.max()) + 1, answer_tokens, sp, (), False)
+    torch.cuda.synchronize(device); host_dec = (time.perf_counter() - b) / max(1, answer_tokens - 1)
     llm.close()
     T, p_s, d_s = len(ids), float(np.median(pre)), float(np.median(dec))
     return {
@@ -220,9 +227,10 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
         "prefill_ms": round(p_s * 1e3, 2), "prefill_includes_vision": bool(vision),
         "prefill_tokens_per_s": round(T / p_s), "prefill_tflops": round(2.0 * stream * T / (p_s - (vis_ms or 0.0) * 1e-3) / 1e12, 1),
         "decode_ms_per_token": round(d_s * 1e3, 3), "decode_tokens_per_s": round(1.0 / d_s, 1),
+        "decode_ms_per_token_host_driven": round(host_dec * 1e3, 3),
         "queries_per_s": round(1.0 / float(np.median(tot)), 3),
         "queries_per_s_at_2048_tokens": round(1.0 / (p_s + 2047 * d_s), 4),
-        "roofline": {"bound": "hbm", "kernel": "decode step: vr::gemm_skinny_kernel (M = 1 weight streaming) + attention + norms",
+        "roofline": {"bound": "hbm", "kernel": "decode step (one captured hipGraph): vr::gemm_skinny_kernel (M = 1 weight streaming) + attention + norms + sampling",
                      "achieved": round(stream * 2 / d_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(stream * 2 / d_s / 8e12, 4),
                      "bytes_per_token": stream * 2}}
 
@@ -503,8 +511,50 @@ class LLM:
         p = (C.c_int32 * 3)(position, position, position)
         _lib.check(self._lib.vg_decode(self._h, int(token), p, None), "vg_decode")
 
+    # ---- free-running steps (vg_run_*): no host round trip per token -------------------------------------------
+    def run_begin(self, position: int, sp: SamplingParams, first_step: int = 1) -> None:
+        _lib.check(self._lib.vg_run_begin(self._h, int(position), float(sp.temperature), float(sp.repetition_penalty), int(sp.seed),
+                                          int(first_step), None), "vg_run_begin")
+
+    def run_step(self) -> None:
+        _lib.check(self._lib.vg_run_step(self._h), "vg_run_step")
+
+    def run_token(self, index: int) -> int:
+        tok = C.c_int32()
+        _lib.check(self._lib.vg_run_token(self._h, int(index), C.byref(tok)), "vg_run_token")
+        return int(tok.value)
+
+    def run_end(self) -> None:
+        _lib.check(self._lib.vg_run_end(self._h), "vg_run_end")
+
+    def _continue(self, first: int, nxt: int, limit: int, sp: SamplingParams, stops, pipelined: bool) -> List[int]:
+        """The tokens after the first one.  pipelined: captured decode + sample steps, one step enqueued ahead of the
+        token being inspected (a stop token costs at most one unused step); else one vg_decode / vg_sample pair per token."""
+        toks = [first]
+        if first in stops or limit <= 1:
+            return toks
+        if not pipelined:
+            for step in range(1, limit):
+                self.decode(toks[-1], nxt)
+                nxt += 1
+                toks.append(self.sample(sp, step))
+                if toks[-1] in stops:
+                    break
+            return toks
+        self.run_begin(nxt, sp, 1)
+        issued = got = 0
+        self.run_step(); issued += 1
+        while got < issued:
+            if issued < limit - 1:
+                self.run_step(); issued += 1
+            toks.append(self.run_token(got)); got += 1
+            if toks[-1] in stops:
+                break
+        self.run_end()
+        return toks
+
     # ---- predict.py:147 ------------------------------------------------------------------------------------
-    def generate(self, prompts, sampling_params: Optional[SamplingParams] = None) -> List[RequestOutput]:
+    def generate(self, prompts, sampling_params: Optional[SamplingParams] = None, pipelined: bool = True) -> List[RequestOutput]:
         sp = sampling_params or SamplingParams()
         stops = set(sp.stop_token_ids if sp.stop_token_ids is not None else self.cfg.eos_token_ids)
         outs = []
@@ -520,15 +570,8 @@ class LLM:
             else:
                 pos3 = self.prefill(ids, mm.get("image_embeds", ()), mm.get("image_grids", ()), pr.get("positions"))
             nxt = int(pos3.max()) + 1
-            toks: List[int] = []
-            room = self.max_model_len - len(ids)
-            for step in range(min(sp.max_tokens, room)):
-                tok = self.sample(sp, step)
-                toks.append(tok)
-                if tok in stops or step + 1 == min(sp.max_tokens, room):
-                    break
-                self.decode(tok, nxt)
-                nxt += 1
+            limit = min(sp.max_tokens, self.max_model_len - len(ids))
+            toks: List[int] = self._continue(self.sample(sp, 0), nxt, limit, sp, stops, pipelined) if limit > 0 else []
             text = self.detokenize(toks) if self.detokenize else ""
             outs.append(RequestOutput([CompletionOutput(toks, text)], ids))
         return outs
