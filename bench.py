@@ -333,7 +333,7 @@ def main():
                 e_.close()
         except Exception as e:   # informational
             result["extras_error"] = repr(e)
-        # BASELINE config 5, language-model part: EVisRAG-7B-shaped generation over the top-5 pages
+        # BASELINE config 5: EVisRAG-7B-shaped generation over the top-5 pages (vision tower + language model)
         try:
             from visrag_amd.evisrag import bench_generate
             result["evisrag_generate"] = bench_generate(5, 64, 2, local_rank)
