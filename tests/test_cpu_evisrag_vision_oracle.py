@@ -203,3 +203,50 @@ def test_head_slot_layout_reproduces_the_oracle():
         out[s:e] = torch.einsum("hqk,khd->qhd", a, vp[s:e])
     got = out.reshape(96, nh * 128) @ Pp.T + w[b + "attn.proj.bias"]
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LLM(model=<checkpoint directory>): the host-side reader (configs, key layout, tokenizer)
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_checkpoint_directory_reader(tmp_path):
+    from tests.evisrag_ckpt_util import make_tiny_checkpoint
+    from visrag_amd.evisrag import gen_weight_specs, iter_checkpoint_weights, load_tokenizer, read_checkpoint_configs
+    d = str(tmp_path / "ckpt")
+    made = make_tiny_checkpoint(d)
+    cfg, vc, tied = read_checkpoint_configs(d)
+    t, v = made["cfg"], made["vcfg"]
+    assert (cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size,
+            cfg.vocab_size) == (t.hidden_size, t.num_hidden_layers, t.num_attention_heads, t.num_key_value_heads,
+                                t.intermediate_size, t.vocab_size)
+    assert tuple(cfg.mrope_section) == tuple(t.mrope_section) and cfg.rope_theta == t.rope_theta and cfg.image_token_id == 5
+    assert cfg.eos_token_ids == (3, 4) and tied is False                 # generation_config.json wins over config.json
+    assert (vc.depth, vc.hidden_size, vc.num_heads, vc.intermediate_size, vc.out_hidden_size, vc.window_size, vc.in_channels) == \
+           (v.depth, v.hidden_size, v.num_heads, v.intermediate_size, 256, v.window_size, 3)
+    assert tuple(vc.fullatt_block_indexes) == tuple(v.fullatt_block_indexes)
+    assert (vc.min_pixels, vc.max_pixels) == (56 * 56, 28 * 28 * 24)
+    # transformers-4.51 key names come out in the layout vg_load_weight reads, every tensor once, values intact
+    got = dict(iter_checkpoint_weights(d, tied))
+    want = set(gen_weight_specs(cfg)) | {k for k in made["weights"] if k.startswith("model.visual.")}
+    assert set(got) == want
+    k = "model.language_model.layers.1.mlp.down_proj.weight"
+    assert torch.equal(got[k], made["weights"][k])
+    # the nested layout of later transformers versions reads the same
+    import json
+    j = json.load(open(os.path.join(d, "config.json")))
+    text = {kk: j.pop(kk) for kk in ["hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "intermediate_size",
+                                    "vocab_size", "rms_norm_eps", "rope_theta", "rope_scaling", "tie_word_embeddings"]}
+    text["rope_parameters"] = {"rope_type": "default", "rope_theta": text.pop("rope_theta"), "mrope_section": text.pop("rope_scaling")["mrope_section"]}
+    j["text_config"] = text
+    d2 = str(tmp_path / "ckpt2")
+    os.makedirs(d2)
+    json.dump(j, open(os.path.join(d2, "config.json"), "w"))
+    cfg2, vc2, _ = read_checkpoint_configs(d2)
+    cfg2.eos_token_ids = cfg.eos_token_ids
+    assert cfg2 == cfg and vc2.depth == vc.depth and vc2.max_pixels == 28 * 28 * 1280      # no preprocessor_config: defaults
+    # tokenizer: the vision special tokens are single ids, one <|image_pad|> per image
+    tok = load_tokenizer(d)
+    ids = tok("w20 w21 <|vision_start|><|image_pad|><|vision_end|> w22")["input_ids"]
+    assert ids == [20, 21, 6, 5, 7, 22]
+    assert tok.decode([20, 3, 21], skip_special_tokens=True) == "w20 w21"
+    assert load_tokenizer(d2) is None

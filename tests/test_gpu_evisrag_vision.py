@@ -162,3 +162,32 @@ def test_errors(setup):
         llm.encode_images(np.zeros((24 * 24, 1176), np.float32), np.array([[1, 24, 24]], np.int32))
     with pytest.raises(ValueError):
         llm.prefill_images([1, 2, 3], _pixels(g), g["grids"])        # no placeholders for three images
+
+
+def test_llm_from_checkpoint_directory_with_text_prompt(setup, tmp_path):
+    """predict.py:112-147 as written: LLM(model=<directory>), a chat-templated prompt STRING with one <|image_pad|> per
+    page, PIL pages in multi_modal_data, .outputs[0].text out — against the same model built from a GenConfig + weights
+    and fed token ids."""
+    from PIL import Image
+    from tests.evisrag_ckpt_util import make_tiny_checkpoint
+    from visrag_amd.evisrag import LLM, SamplingParams
+    g, cfg, vcfg, llm = setup
+    d = str(tmp_path / "ckpt")
+    make_tiny_checkpoint(d)
+    rng = np.random.default_rng(9)
+    pages = [Image.fromarray(rng.integers(0, 256, (150, 97, 3), dtype=np.uint8)), Image.fromarray(rng.integers(0, 256, (60, 120, 3), dtype=np.uint8))]
+    prompt = "w20 w21 <|vision_start|><|image_pad|><|vision_end|> w22 <|vision_start|><|image_pad|><|vision_end|> w23 w24"
+    ids = [20, 21, 6, 5, 7, 22, 6, 5, 7, 23, 24]
+    sp = SamplingParams(temperature=0.0, repetition_penalty=1.05, max_tokens=12)
+    ck = LLM(model=d, tensor_parallel_size=1, dtype="bfloat16", limit_mm_per_prompt={"image": 5, "video": 0}, max_model_len=512,
+             max_prefill=256, max_vision_rows=512)
+    try:
+        assert ck.cfg.eos_token_ids == (3, 4) and ck.vision.max_pixels == 28 * 28 * 24
+        out = ck.generate([{"prompt": prompt, "multi_modal_data": {"image": pages}}], sampling_params=sp)[0]
+    finally:
+        ck.close()
+    sp_ref = SamplingParams(temperature=0.0, repetition_penalty=1.05, max_tokens=12, stop_token_ids=(3, 4))
+    ref = llm.generate([{"prompt_token_ids": ids, "multi_modal_data": {"image": pages}}], sp_ref)[0]
+    assert out.prompt_token_ids == ref.prompt_token_ids
+    assert out.outputs[0].token_ids == ref.outputs[0].token_ids
+    assert out.outputs[0].text == " ".join(f"w{t}" for t in out.outputs[0].token_ids if t >= 8)

@@ -6,8 +6,13 @@
     outs = llm.generate([{"prompt_token_ids": ids, "multi_modal_data": {...}}], sampling_params=sp)   # predict.py:147
     outs[0].outputs[0].token_ids / .text
 
-What this module does NOT contain: the tokenizer / chat template (the reference gets them from the checkpoint directory
-through `AutoProcessor`; there is no checkpoint on this box).  A prompt is therefore token ids, plus its page images:
+`LLM(model=<checkpoint directory>)` reads a HuggingFace Qwen2.5-VL checkpoint the way vLLM does for predict.py:112: config.json
+(language model + vision_config), preprocessor_config.json (the image processor's pixel limits and normalisation),
+generation_config.json (stop tokens), the *.safetensors shards, and the directory's tokenizer — after which a prompt may be
+the chat-templated STRING of predict.py:134-145 (`{"prompt": prompt, "multi_modal_data": {"image": image_inputs}}`).  The
+chat template itself stays with the caller's `AutoProcessor`, as in the reference.  `LLM(model=GenConfig(...), weights=...)`
+builds a model without a directory (tests, benchmarks: there is no checkpoint on this box); then a prompt is token ids.
+Either way the page images travel as:
   * `{"image": [PIL.Image, ...]}` like predict.py:140-145 — with a vision tower attached (`LLM(..., vision=VisionConfig())`)
     the images go through the Qwen2-VL image processing (`process_images`: smart_resize, bicubic resize, normalise,
     patchify) and the HIP tower; every `image_token_id` in the ids stands for one image (the chat template's single
@@ -78,6 +83,99 @@ class VisionConfig:
                                    self.in_channels, self.patch_size, self.temporal_patch_size, self.spatial_merge_size,
                                    self.window_size, len(full), (C.c_int32 * 16)(*(full + [0] * (16 - len(full)))), int(max_rows),
                                    self.rms_norm_eps)
+
+
+def remap_checkpoint_key(k: str) -> str:
+    """State-dict key of any Qwen2.5-VL checkpoint layout -> the layout vg_load_weight reads ("model.language_model.*",
+    "model.visual.*", "lm_head.weight").  Checkpoints written by transformers < 4.52 (EVisRAG's 4.51.3) use
+    "model.layers.*" / "model.embed_tokens.*" / "model.norm.*" and "visual.*"."""
+    if k.startswith("visual."):
+        return "model." + k
+    if k.startswith("model.") and not k.startswith(("model.language_model.", "model.visual.")):
+        return "model.language_model." + k[len("model."):]
+    return k
+
+
+def read_checkpoint_configs(path: str):
+    """(GenConfig, VisionConfig or None, tie_word_embeddings) from a checkpoint directory: config.json in the flat layout
+    of transformers 4.51 or with "text_config" / "rope_parameters" of later versions; preprocessor_config.json and
+    generation_config.json when present."""
+    import json
+    import os
+    with open(os.path.join(path, "config.json")) as f:
+        j = json.load(f)
+    t = dict(j)
+    t.update(j.get("text_config") or {})
+    rope = t.get("rope_parameters") or t.get("rope_scaling") or {}
+    g = GenConfig()
+    cfg = GenConfig(
+        hidden_size=t.get("hidden_size", g.hidden_size), num_hidden_layers=t.get("num_hidden_layers", g.num_hidden_layers),
+        num_attention_heads=t.get("num_attention_heads", g.num_attention_heads),
+        num_key_value_heads=t.get("num_key_value_heads", g.num_key_value_heads),
+        intermediate_size=t.get("intermediate_size", g.intermediate_size), vocab_size=t.get("vocab_size", g.vocab_size),
+        rms_norm_eps=t.get("rms_norm_eps", g.rms_norm_eps), rope_theta=rope.get("rope_theta", t.get("rope_theta", g.rope_theta)),
+        mrope_section=tuple(rope.get("mrope_section", g.mrope_section)), image_token_id=j.get("image_token_id", g.image_token_id))
+    eos = j.get("eos_token_id", t.get("eos_token_id"))
+    gpath = os.path.join(path, "generation_config.json")
+    if os.path.exists(gpath):
+        with open(gpath) as f:
+            eos = json.load(f).get("eos_token_id", eos)
+    if eos is not None:
+        cfg.eos_token_ids = tuple(eos) if isinstance(eos, (list, tuple)) else (int(eos),)
+    vision = None
+    v = j.get("vision_config")
+    if v:
+        d = VisionConfig()
+        vision = VisionConfig(
+            depth=v.get("depth", d.depth), hidden_size=v.get("hidden_size", d.hidden_size), num_heads=v.get("num_heads", d.num_heads),
+            intermediate_size=v.get("intermediate_size", d.intermediate_size),
+            out_hidden_size=v.get("out_hidden_size", cfg.hidden_size), in_channels=v.get("in_channels", v.get("in_chans", d.in_channels)),
+            patch_size=v.get("patch_size", d.patch_size), temporal_patch_size=v.get("temporal_patch_size", d.temporal_patch_size),
+            spatial_merge_size=v.get("spatial_merge_size", d.spatial_merge_size), window_size=v.get("window_size", d.window_size),
+            fullatt_block_indexes=tuple(v.get("fullatt_block_indexes", d.fullatt_block_indexes)))
+        ppath = os.path.join(path, "preprocessor_config.json")
+        if os.path.exists(ppath):
+            with open(ppath) as f:
+                pj = json.load(f)
+            size = pj.get("size") or {}
+            vision.min_pixels = int(pj.get("min_pixels", size.get("shortest_edge", vision.min_pixels)))
+            vision.max_pixels = int(pj.get("max_pixels", size.get("longest_edge", vision.max_pixels)))
+            vision.image_mean = tuple(pj.get("image_mean", vision.image_mean))
+            vision.image_std = tuple(pj.get("image_std", vision.image_std))
+    return cfg, vision, bool(t.get("tie_word_embeddings", j.get("tie_word_embeddings", False)))
+
+
+def iter_checkpoint_weights(path: str, tie_word_embeddings: bool = False):
+    """(key for vg_load_weight, CPU tensor) over the *.safetensors shards of a checkpoint directory; a tied lm_head is
+    the embedding table a second time."""
+    import os
+    from safetensors import safe_open
+    files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    have_head = False
+    for fn in files:
+        with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
+            for k in f.keys():
+                key = remap_checkpoint_key(k)
+                have_head |= key == "lm_head.weight"
+                t = f.get_tensor(k)
+                yield key, t
+                if tie_word_embeddings and key == "model.language_model.embed_tokens.weight":
+                    have_head = True
+                    yield "lm_head.weight", t
+    if not have_head:
+        raise KeyError(f"no lm_head.weight under {path} (and tie_word_embeddings is false)")
+
+
+def load_tokenizer(path: str):
+    """The checkpoint directory's tokenizer (what vLLM tokenizes predict.py's prompt string with); None if the directory
+    has none."""
+    import os
+    if not any(os.path.exists(os.path.join(path, f)) for f in ("tokenizer.json", "vocab.json", "tokenizer.model")):
+        return None
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(path, local_files_only=True)
 
 
 @dataclass
@@ -371,8 +469,18 @@ class LLM:
             raise ValueError("one GPU per model (predict.py:114 uses tensor_parallel_size=1)")
         if dtype not in ("bfloat16", "bf16"):
             raise ValueError("the generator computes in bf16 (predict.py:115)")
+        self.tokenizer = None
+        if isinstance(model, str):                     # a checkpoint directory, like predict.py:112's model_path
+            model_dir = model
+            model, ck_vision, tied = read_checkpoint_configs(model_dir)
+            vision = vision or ck_vision
+            if weights is None:
+                weights = iter_checkpoint_weights(model_dir, tied)
+            self.tokenizer = load_tokenizer(model_dir)
+            if detokenize is None and self.tokenizer is not None:
+                detokenize = lambda ids, _t=self.tokenizer: _t.decode(ids, skip_special_tokens=True)       # noqa: E731  (vLLM's default)
         if not isinstance(model, GenConfig):
-            raise TypeError("model: a GenConfig (no checkpoint reader for the generator yet); pass weights=iterable of (name, tensor)")
+            raise TypeError("model: a checkpoint directory or a GenConfig (+ weights=iterable of (name, tensor))")
         self.cfg: GenConfig = model
         self.max_images = (limit_mm_per_prompt or {"image": 5}).get("image", 5)
         self.device = int(device)
@@ -403,6 +511,7 @@ class LLM:
         """weights: iterable of (HF state-dict key, torch tensor f32/bf16 on the CPU or on this GPU)."""
         import torch
         for name, t in (weights.items() if hasattr(weights, "items") else weights):
+            name = remap_checkpoint_key(name)
             if t.dtype not in (torch.float32, torch.bfloat16):
                 t = t.float()
             t = t.contiguous()
@@ -559,7 +668,12 @@ class LLM:
         stops = set(sp.stop_token_ids if sp.stop_token_ids is not None else self.cfg.eos_token_ids)
         outs = []
         for pr in prompts:
-            ids = list(pr["prompt_token_ids"])
+            if pr.get("prompt_token_ids") is not None:
+                ids = list(pr["prompt_token_ids"])
+            elif self.tokenizer is not None:        # predict.py:143: the chat-templated string
+                ids = list(self.tokenizer(pr["prompt"])["input_ids"])
+            else:
+                raise ValueError("a text prompt needs the checkpoint's tokenizer: LLM(model=<checkpoint directory>), or pass prompt_token_ids")
             mm = pr.get("multi_modal_data") or {}
             if mm.get("image") is not None or mm.get("pixel_values") is not None:
                 if self.vision is None:
