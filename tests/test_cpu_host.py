@@ -252,3 +252,64 @@ def test_evisrag_rope_index_layout():
     import pytest
     with pytest.raises(ValueError):
         rope_index(ids, IMG, [(2, 3)])
+
+
+def test_evisrag_token_loop_and_placeholder_expansion():
+    """The host logic of evisrag.LLM that needs no GPU: one-placeholder-per-image expansion, and the token loop that keeps
+    one captured step enqueued ahead of the token it inspects (driven here by a stub in place of the library)."""
+    from types import SimpleNamespace
+
+    from visrag_amd.evisrag import LLM, GenConfig, SamplingParams
+
+    me = SimpleNamespace(cfg=GenConfig(image_token_id=5))
+    assert LLM.expand_image_tokens(me, [1, 5, 2, 5, 3], [2, 3]) == [1, 5, 5, 2, 5, 5, 5, 3]
+    assert LLM.expand_image_tokens(me, [1, 5, 5, 2, 5, 5, 5, 3], [2, 3]) == [1, 5, 5, 2, 5, 5, 5, 3]      # already expanded
+    with pytest.raises(ValueError):
+        LLM.expand_image_tokens(me, [1, 5, 2], [2, 3])
+
+    class Stub:
+        """Produces the token stream 100, 101, ...; counts what the loop enqueues."""
+        def __init__(self):
+            self.issued = self.ended = 0
+            self.begun = None
+            self.max_ahead = 0
+            self.collected = 0
+
+        def run_begin(self, position, sp, first_step):
+            self.begun = (position, first_step)
+
+        def run_step(self):
+            self.issued += 1
+            self.max_ahead = max(self.max_ahead, self.issued - self.collected)
+
+        def run_token(self, i):
+            assert i == self.collected and i < self.issued
+            self.collected += 1
+            return 101 + i
+
+        def run_end(self):
+            self.ended += 1
+
+        def decode(self, tok, pos):
+            self.issued += 1
+            self.last = (tok, pos)
+
+        def sample(self, sp, step):
+            return 100 + step
+
+    sp = SamplingParams(temperature=0.0)
+    for pipelined in (True, False):
+        s = Stub()
+        assert LLM._continue(s, 100, 40, 6, sp, set(), pipelined) == [100, 101, 102, 103, 104, 105]
+        assert s.issued == 5                                        # limit 6 tokens = the first one + five steps, never more
+        if pipelined:
+            assert s.begun == (40, 1) and s.ended == 1 and s.max_ahead == 2
+        else:
+            assert s.last == (104, 44)
+        s = Stub()
+        assert LLM._continue(s, 100, 40, 50, sp, {103}, pipelined) == [100, 101, 102, 103]
+        assert s.issued == (4 if pipelined else 3)                  # a stop token costs at most one step already in flight
+        s = Stub()
+        assert LLM._continue(s, 100, 40, 50, sp, {100}, pipelined) == [100] and s.issued == 0
+        s = Stub()
+        assert LLM._continue(s, 100, 40, 1, sp, set(), pipelined) == [100] and s.issued == 0
