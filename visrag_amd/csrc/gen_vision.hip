@@ -11,8 +11,8 @@
 //   * rows are put into WINDOW ORDER once, while the pixel rows are converted to bf16 (gather_rows_bf16), so every
 //     attention segment — a window or an image — is a contiguous row range handed to the flash-attention kernel as
 //     cu_q / cu_kv; the merger's output is scattered back into image order straight into the prefill's embedding rows.
-//   * head_dim 80 (7B), 64 and 128 run on the attention kernel's own configurations.  Any other head_dim (a multiple
-//     of 4 up to 128; the test fixture's 40) gets a 128-wide slot per head: the q / k / v weight rows of a head are
+//   * head_dim 80 (every released Qwen2.5-VL tower: 1280 / 16) runs on the attention kernel's own head_dim-80 form.  Any
+//     other head_dim (a multiple of 4 up to 128; the test fixture's 40) gets a 128-wide slot per head: the q / k / v weight rows of a head are
 //     packed as two halves at slot rows [0, hd/2) and [64, 64 + hd/2) (zeros elsewhere) and the output projection's
 //     columns likewise, so rotate-half pairs (c, c + hd/2) land on slot pairs (p, p + 64), the padded channels are
 //     exact zeros through q.k and p.v, and the softmax scale stays 1/sqrt(hd).
@@ -149,7 +149,7 @@ extern "C" int vg_vision_create(vg_model_t m, const vg_vision_config_t* cfg) {
     auto bail = [&](int rc) { vision_destroy(m); return rc; };
     v->c = c;
     v->H = c.hidden_size; v->Hp = pad128(v->H); v->heads = c.num_heads; v->hd = v->H / v->heads; v->half = v->hd / 2;
-    v->hh = (v->hd == 64 || v->hd == 80 || v->hd == 128) ? v->half : 64;      // native attention head_dim, or a 128-wide slot
+    v->hh = v->hd == 80 ? v->half : 64;      // the 7B / 3B / 72B towers' head_dim on its own attention form; else a 128-wide slot
     v->AD = v->heads * 2 * v->hh;
     v->QKVp = pad128(3 * v->AD); v->ATp = pad128(v->AD);                       // row strides of the qkv / attention-output rows
     v->I = c.intermediate_size; v->Ip = pad128(v->I);
