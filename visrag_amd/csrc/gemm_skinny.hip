@@ -32,6 +32,9 @@ constexpr int SK_W_AUX = VR_SKINNY_W_AUX;
 
 }  // namespace
 
+// SWIGLU (ksplit 1 only): W rows interleaved in blocks of 16 ([16 gate | 16 up | ...], EPI_SWIGLU's layout); the tile's
+// epilogue writes act = silu(gate) * up as bf16 [M][ldo] — no fp32 plane, no swiglu_sum launch.
+template <bool SWIGLU>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = (p.N + 255) / 256;
@@ -82,6 +85,27 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
         }
     }
     // acc[j][r] = out[m = fr][n = n0 + wave*64 + j*16 + fq*4 + r]; bias rides with split 0
+    if constexpr (SWIGLU) {
+        if (fr < p.M) {
+            bf16_t* act = (bf16_t*)p.out + (size_t)fr * p.ldo;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int n = n0 + wave * 64 + jj * 32;          // a [16 gate | 16 up] block pair = 16 columns of act
+                if (n < p.N) {
+                    f32x4 g = acc[2 * jj], u = acc[2 * jj + 1];
+                    if (p.bias) {
+                        g += *reinterpret_cast<const f32x4*>(p.bias + n + fq * 4);
+                        u += *reinterpret_cast<const f32x4*>(p.bias + n + 16 + fq * 4);
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f2bf(g[r] / (1.0f + __expf(-g[r])) * u[r]);   // (swiglu_sum_kernel's expression)
+                    *reinterpret_cast<bf16x4*>(act + n / 2 + fq * 4) = o;
+                }
+            }
+        }
+        return;
+    }
     if (fr < p.M) {
         float* out = (float*)p.out + (size_t)split * p.split_stride + (size_t)fr * p.ldo;
 #pragma unroll
@@ -98,15 +122,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 
 // fp32 planes out[split][M][ldo]; M <= 16 (A and W rows readable up to 16 / the next multiple of 256), K % 64 == 0; split s
 // covers K-steps [s * ceil(steps / ksplit), ...) — a split past the end writes a plane of zeros (+ bias for split 0)
-hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s) {
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     if (a.M <= 0) return hipSuccess;
+    if (swiglu && (ks != 1 || a.N % 32)) return hipErrorInvalidValue;
     if (a.M > 16 || a.N % 4 || a.K % GEMM_BK || a.rowmap || a.rowbias) return hipErrorInvalidValue;
     const size_t tn = (a.N + 255) / 256;
     if (tn * 256 * (size_t)a.ldw * 2 >= (1ull << 31) || 16 * (size_t)a.lda * 2 >= (1ull << 31)) return hipErrorInvalidValue;
-    static unsigned long long attr = 0;     // bit d: set on device d
-    set_max_dynamic_lds((const void*)gemm_skinny_kernel, SK_SMEM, attr);
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a);
+    static unsigned long long attr = 0, attr_sw = 0;     // bit d: set on device d
+    if (swiglu) {
+        set_max_dynamic_lds((const void*)gemm_skinny_kernel<true>, SK_SMEM, attr_sw);
+        hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3((unsigned)tn), dim3(256), SK_SMEM, s, a);
+    } else {
+        set_max_dynamic_lds((const void*)gemm_skinny_kernel<false>, SK_SMEM, attr);
+        hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a);
+    }
     return hipGetLastError();
 }
 

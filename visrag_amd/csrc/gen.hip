@@ -248,9 +248,14 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
         const int N2 = L.gu.n_pad;
         GemmArgs g = gen_gemm_args(m->w_xn.p, E, L.gu, T, part, N2);
         g.ksplit = choose_ksplit(N2, E, VR_KS_GU);
-        g.split_stride = (size_t)N2 * T;
-        HIPCHK(launch_gemm_skinny(g, s));
-        HIPCHK(launch_swiglu_sum(part, g.ksplit, (size_t)N2 * T, N2, T, m->I, m->w_act.p, Ip, s));
+        if (g.ksplit == 1) {                        // the usual case (more tiles than a split would help): SwiGLU in the tile's epilogue
+            g.out = m->w_act.p; g.ldo = Ip;
+            HIPCHK(launch_gemm_skinny(g, s, true));
+        } else {
+            g.split_stride = (size_t)N2 * T;
+            HIPCHK(launch_gemm_skinny(g, s));
+            HIPCHK(launch_swiglu_sum(part, g.ksplit, (size_t)N2 * T, N2, T, m->I, m->w_act.p, Ip, s));
+        }
         GemmArgs a = gen_gemm_args(m->w_act.p, Ip, L.down, T, part, E);
         a.ksplit = choose_ksplit(E, L.down.k_pad, VR_KS_DOWN);
         a.split_stride = (size_t)E * T;

@@ -47,11 +47,17 @@ __global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restri
     if (parts) {
         x1 = bias ? bias[col + lane] : 0.f;
         x2 = bias ? bias[col + 64 + lane] : 0.f;
-        for (int s = 0; s < n_parts; ++s) {
-            const float* row = parts + (size_t)s * plane_stride + (size_t)t * ld + col;
-            x1 += row[lane];
-            x2 += row[64 + lane];
+        // independent loads, ordered sum: eight planes in flight at a time
+        const float* row = parts + (size_t)t * ld + col + lane;
+        int s = 0;
+        for (; s + 8 <= n_parts; s += 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a[i] = row[(size_t)(s + i) * plane_stride]; b[i] = row[(size_t)(s + i) * plane_stride + 64]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { x1 += a[i]; x2 += b[i]; }
         }
+        for (; s < n_parts; ++s) { x1 += row[(size_t)s * plane_stride]; x2 += row[(size_t)s * plane_stride + 64]; }
     } else {
         const bf16_t* row = src + (size_t)t * ld + col;
         x1 = bf2f(row[lane]);
@@ -263,12 +269,21 @@ __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, co
                                     bf16_t* __restrict__ out, const int* __restrict__ S_dev) {
     if (S_dev) S = *S_dev;
     const int h = blockIdx.x, d = threadIdx.x;        // 128 threads: one per channel of the head
+    // every load up front (S <= GEN_ATT_SPLITS): the sums below then run without waiting on memory
+    float l[GEN_ATT_SPLITS], pv[GEN_ATT_SPLITS];
+#pragma unroll
+    for (int s = 0; s < GEN_ATT_SPLITS; ++s) {
+        l[s] = s < S ? lse[s * heads + h] : -INFINITY;
+        pv[s] = s < S ? bf2f(part[(size_t)s * ldp + h * 128 + d]) : 0.f;
+    }
     float mx = -INFINITY;
-    for (int s = 0; s < S; ++s) mx = fmaxf(mx, lse[s * heads + h]);
+#pragma unroll
+    for (int s = 0; s < GEN_ATT_SPLITS; ++s) mx = fmaxf(mx, l[s]);
     float num = 0.f, den = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float w = exp2f(lse[s * heads + h] - mx);
-        num += w * bf2f(part[(size_t)s * ldp + h * 128 + d]);
+#pragma unroll
+    for (int s = 0; s < GEN_ATT_SPLITS; ++s) {
+        const float w = s < S ? exp2f(l[s] - mx) : 0.f;
+        num += w * pv[s];
         den += w;
     }
     out[h * 128 + d] = f2bf(num / den);

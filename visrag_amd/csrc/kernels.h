@@ -41,7 +41,8 @@ bool gemm256w_fits(const GemmArgs& a, int tile_cols);   // its 32-bit LDS-DMA of
 hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
 
 // M <= 16 rows (gemm_skinny.hip): the decode step's weight streamer; fp32 planes out[split][M][ldo] (+ bias with split 0)
-hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s);
+// swiglu (ksplit 1, 16-row [gate | up] interleaved W): out = bf16 act [M][ldo] = silu(gate) * up instead of a plane
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu = false);
 // act = silu(gate) * up from the fp32 planes of a gate/up GEMM over 16-row interleaved weights
 hipError_t launch_swiglu_sum(const float* parts, int n_parts, size_t plane_stride, int ldp, int M, int I, void* act, int lda,
                              hipStream_t s);

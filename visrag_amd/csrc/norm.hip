@@ -150,8 +150,19 @@ __global__ __launch_bounds__(1024) void rmsnorm_accum_row_kernel(float* __restri
     const int row = blockIdx.x, c = threadIdx.x, nv = dim >> 2;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (c < nv) {
-        f32x4 acc = reinterpret_cast<const f32x4*>(partial + (size_t)row * ldp)[c];
-        for (int sp = 1; sp < nsplit; ++sp) acc += reinterpret_cast<const f32x4*>(partial + sp * split_stride + (size_t)row * ldp)[c];
+        // the planes of a column are independent loads but an ordered sum: fetch eight at a time, then add in plane order
+        // (a plain loop waits for every load before it asks for the next: 18 planes x ~0.3 us)
+        const float* pc = partial + (size_t)row * ldp + (size_t)c * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(pc);
+        int sp = 1;
+        for (; sp + 8 <= nsplit; sp += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = *reinterpret_cast<const f32x4*>(pc + (size_t)(sp + i) * split_stride);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += t[i];
+        }
+        for (; sp < nsplit; ++sp) acc += *reinterpret_cast<const f32x4*>(pc + (size_t)sp * split_stride);
         f32x4* xr = reinterpret_cast<f32x4*>(x + (size_t)row * ldx);
         v = xr[c] + alpha * acc;
         xr[c] = v;
