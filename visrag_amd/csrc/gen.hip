@@ -22,6 +22,12 @@
 
 static int end_run(vg_model_s* m);      // waits for the steps of a free run (vg_run_*) still in flight
 
+// the captured decode step holds device pointers by value: anything that may move a buffer drops it
+static void drop_graph(vg_model_s* m) {
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+}
+
 // decode (gemm_skinny.hip): how many K ranges a GEMM's 256-column tiles are cut into.  One workgroup fits on a CU (its
 // four LDS stages), so the fastest shape is ONE balanced round of workgroups with K loops as long as that allows —
 // measured on the 7B layer (ms per token): gate/up 148 tiles as 148 x 56 K-steps 3.74, 296 x 28 (a second round of 40)
@@ -93,8 +99,7 @@ extern "C" int vg_destroy(vg_model_t m) {
     if (!m) return VR_OK;
     (void)hipSetDevice(m->device);
     if (m->run_stream) (void)hipStreamSynchronize(m->run_stream);
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
+    drop_graph(m);
     for (auto& e : m->run_ev)
         if (e) (void)hipEventDestroy(e);
     if (m->h_tokens) (void)hipHostFree(m->h_tokens);
@@ -121,6 +126,8 @@ extern "C" int vg_load_weight(vg_model_t m, const char* name_c, const void* data
     VRCHK(stage(data, numel * (bf ? 2 : 4), on_device, st));
     const void* src = st.dev;
     m->finalized = false;
+    VRCHK(end_run(m));
+    drop_graph(m);                      // (re)loading a tensor may reallocate it
     if (vis_key) return vision_load_weight(m, name.substr(name.find("visual.") + 7), src, bf, shape, ndim, numel);
     const std::string pre = "model.language_model.";
     if (name == pre + "embed_tokens.weight") {
@@ -391,8 +398,7 @@ extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penal
 // ---- free-running generation ------------------------------------------------------------------------------------
 static int capture_step(vg_model_s* m, float temperature, float penalty, unsigned long long seed) {
     if (m->graph_exec && m->g_temp == temperature && m->g_pen == penalty && m->g_seed == seed) return VR_OK;
-    if (m->graph_exec) { HIPCHK(hipGraphExecDestroy(m->graph_exec)); m->graph_exec = nullptr; }
-    if (m->graph) { HIPCHK(hipGraphDestroy(m->graph)); m->graph = nullptr; }
+    drop_graph(m);
     HIPCHK(hipStreamBeginCapture(m->run_stream, hipStreamCaptureModeRelaxed));
     const int rc = enqueue_decode(m, m->run_stream, true, temperature, penalty, seed);
     hipGraph_t g = nullptr;
