@@ -90,7 +90,8 @@ def test_tower_per_image_equals_batched(setup):
     for gr in grids:
         n = int(gr[0] * gr[1] * gr[2])
         one = llm.encode_images(px[r0:r0 + n], gr[None])
-        np.testing.assert_array_equal(one, allrows[t0:t0 + n // 4])
+        # (bit-equal as long as both calls pick the same GEMM tiles; a different tile may round the bf16 steps differently)
+        np.testing.assert_allclose(one, allrows[t0:t0 + n // 4], rtol=0, atol=5e-3 * float(np.abs(allrows).max()))
         r0 += n
         t0 += n // 4
 
