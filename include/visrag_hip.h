@@ -149,18 +149,47 @@ int vr_index_reset(vr_index_t ix);
 int vr_index_add(vr_index_t ix, const float* reps, int64_t n, int32_t on_device, void* stream);
 int vr_index_size(vr_index_t ix, int64_t* n);
 /* For every query the k best rows by inner product: higher score first, lower row id first
- * among equal scores.  Scores are exact fp32 dot products of the fp32 rows (a bf16 MFMA
- * sweep selects candidates, the survivors are re-scored in fp32).
+ * among equal scores — the ranking torch.topk sees over the fp32 matmul of
+ * dense_retriever.py:28-30.  Scores are fp32 dot products of the fp32 rows.  A bf16 MFMA
+ * sweep selects candidates, the survivors are re-scored in fp32, and the selection is
+ * CERTIFIED per query: with |bf16 score - fp32 score| <= eps_rel * |q| * max|row| every row
+ * whose bf16 score could still reach the fp32 top-k is re-scored too; a query whose candidate
+ * lists cannot prove completeness (more near-ties at the k-th score than they hold) is redone
+ * by an exact fp32 pass over the whole index.  The ids are the fp32 ranking's.
  *   queries [nq][dim] float32;  out_scores [nq][k] float32;  out_ids [nq][k] int64
  * (all host or all device per `on_device`).  If the index holds fewer than k rows the
  * tail is filled with score -inf, id -1.  k = 1..1000: up to 26 on the fused sweep (the
  * throughput path; --retrieve_depth 10 in eval.sh), deeper runs on GEMM + radix select. */
 int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k,
                     float* out_scores, int64_t* out_ids, int32_t on_device, void* stream);
+/* The error model of the certification: eps_rel >= 0 replaces the default bound
+ * (2^-8 + 2^-18 + (2 dim + 128) 2^-24: round-to-nearest bf16 operands, fp32 accumulation,
+ * worst case by Cauchy-Schwarz); eps_rel < 0 switches certification off (the bf16 top-(k+6)
+ * re-scored, as in rounds 1-2: tolerance-exact); NaN restores the default. */
+int vr_index_set_search_eps(vr_index_t ix, float eps_rel);
+/* Queries counted since the last reset: out4 = {certified at once, certified after extended
+ * re-scoring, flagged and redone by the exact pass, searched with certification off}. */
+int vr_index_search_stats(vr_index_t ix, int64_t* out4, int32_t reset);
+/* Per-stage HIP-event times of vr_index_search (k <= 26), summed over calls since enabling:
+ * ms5 = {query conversion, threshold pre-pass, sweep, merge + re-scoring, exact pass}.
+ * While enabled every call ends with an event synchronisation. */
+int vr_index_set_search_profile(vr_index_t ix, int32_t enable);
+int vr_index_get_search_profile(vr_index_t ix, double* ms5, int64_t* calls);
+/* The same search with the result packed for the multi-GPU exchange: out_keys [nq][k] uint64,
+ * key = orderable(score) << 32 | ~(row id + id_offset) — larger key = better (higher score,
+ * then lower global id); 0 = no entry.  One 8-byte word per result is what the ranks
+ * all-gather (dense_retriever.py:48-69 exchanges through the file system instead).
+ * id_offset + rows must stay below 2^32 - 1. */
+int vr_index_search_keys(vr_index_t ix, const float* queries, int32_t nq, int32_t k, int64_t id_offset,
+                         uint64_t* out_keys, int32_t on_device, void* stream);
 /* Merge per-shard results (e.g. after an RCCL all-gather): in [n_parts][nq][k] scores and
  * global ids -> out [nq][k], same ordering rule.  Device pointers. */
 int vr_topk_merge(int device_id, const float* scores, const int64_t* ids, int32_t n_parts,
                   int32_t nq, int32_t k, float* out_scores, int64_t* out_ids, void* stream);
+/* The same merge over the packed keys of vr_index_search_keys ([n_parts][nq][k], e.g. the
+ * all-gather's output buffer as it is) -> scores and global ids. */
+int vr_topk_merge_keys(int device_id, const uint64_t* keys, int32_t n_parts, int32_t nq, int32_t k,
+                       float* out_scores, int64_t* out_ids, void* stream);
 
 /* ---- host pre-processing moved to the GPU ------------------- */
 /* Bicubic resize of an 8-bit RGB (HWC) image, bit-exact with Pillow's

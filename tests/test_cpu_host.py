@@ -112,13 +112,14 @@ import os, sys
 sys.path.insert(0, os.environ["VR_ROOT"])
 import numpy as np, torch, torch.distributed as dist
 from oracle import visrag_ret_oracle as O
-from visrag_amd.retriever import merge_topk_host, sharded_search
+from visrag_amd.retriever import merge_keys_host, pack_keys_host, sharded_search
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["VR_PORT"],
                         rank=int(os.environ["VR_RANK"]), world_size=2)
 rank = dist.get_rank()
 rng = np.random.default_rng(0)
 C = rng.standard_normal((400, 16)).astype(np.float32); Q = rng.standard_normal((5, 16)).astype(np.float32)
 C[300] = C[20]                                          # exact tie across the two shards
+Q[4] = -Q[0]                                            # negative scores: the key order must hold below zero too
 lo = rank * 200
 calls = {"n": 0}
 real_gather = dist.all_gather_into_tensor
@@ -127,23 +128,26 @@ def counting_gather(*a, **k):
     return real_gather(*a, **k)
 dist.all_gather_into_tensor = counting_gather
 # the PRODUCT's multi-rank function; only the device pieces are swapped for CPU stand-ins:
-# HipIndex.search -> the oracle's matmul + top-k on this rank's shard, vr_topk_merge -> merge_topk_host
-def local_search(q, k):
-    return O.search_topk(q.numpy(), C[lo:lo + 200], k)
-def merge(all_sc, all_ids):
-    s, i = merge_topk_host(all_sc.numpy(), all_ids.numpy(), all_sc.shape[2])
+# HipIndex.search_keys -> the oracle's matmul + top-k on this rank's shard packed by the host statement of the
+# key format, vr_topk_merge_keys -> merge_keys_host
+def local_search_keys(q, k, id_offset):
+    s, i = O.search_topk(q.numpy(), C[lo:lo + 200], k)
+    return pack_keys_host(s, i, id_offset)
+def merge_keys(keys):
+    s, i = merge_keys_host(keys.numpy(), keys.shape[2])
     return torch.from_numpy(s), torch.from_numpy(i)
-ms, mi = sharded_search(None, torch.from_numpy(Q), 7, id_offset=lo, local_search=local_search, merge=merge)
+ms, mi = sharded_search(None, torch.from_numpy(Q), 7, id_offset=lo, local_search_keys=local_search_keys, merge_keys=merge_keys)
 assert calls["n"] == 1, calls                           # ONE exchange step
 rs, ri = O.search_topk(Q, C, 7)
 assert np.array_equal(mi.numpy(), ri) and np.array_equal(ms.numpy(), rs), rank
-# fewer rows than k on one rank: its tail (-inf, -1) must survive the packed exchange
-def short_search(q, k):                                 # (HipIndex pads a short shard with score -inf, id -1)
+# fewer rows than k on one rank: its tail (empty keys) must survive the packed exchange
+def short_search_keys(q, k, id_offset):                 # (HipIndex pads a short shard with empty slots)
     n = 3 if rank == 1 else 200
     s, i = O.search_topk(q.numpy(), C[lo:lo + n], min(k, n))
     pad = k - s.shape[1]
-    return (np.pad(s, ((0, 0), (0, pad)), constant_values=-np.inf), np.pad(i, ((0, 0), (0, pad)), constant_values=-1))
-ms, mi = sharded_search(None, torch.from_numpy(Q), 7, id_offset=lo, local_search=short_search, merge=merge)
+    return pack_keys_host(np.pad(s, ((0, 0), (0, pad)), constant_values=-np.inf), np.pad(i, ((0, 0), (0, pad)), constant_values=-1),
+                          id_offset)
+ms, mi = sharded_search(None, torch.from_numpy(Q), 7, id_offset=lo, local_search_keys=short_search_keys, merge_keys=merge_keys)
 rs, ri = O.search_topk(Q, np.concatenate([C[:200], C[200:203]]), 7)
 assert np.array_equal(mi.numpy(), ri) and np.array_equal(ms.numpy(), rs), rank
 dist.barrier(); dist.destroy_process_group()

@@ -948,8 +948,18 @@ struct vr_index_s {
     int device = 0, dim = 0;
     int64_t cap = 0, n = 0;
     DevBuf f32, bf16;                 // [cap_pad][dim]
-    DevBuf q32, qbf, cs, ci, ck, os, oi, thr, sbuf;  // query staging / candidates / outputs / thresholds / big-k scores
-    int64_t qcap = 0, ccap = 0, kcap = 0, scap = 0;
+    DevBuf q32, qbf, cs, ci, ck, os, oi, ok, thr, sbuf;  // query staging / candidates / outputs / thresholds / score rows
+    int64_t qcap = 0, ccap = 0, kcap = 0;
+    // certification state (search_common.h): word 0 = largest row norm (f32), word 1 = flag count,
+    // words 2..5 = query counters {certified at once, after extended re-scoring, flagged, uncertified mode}
+    DevBuf cert, flags;
+    int64_t fcap = 0;
+    float eps_rel = -2.f;             // -2: the rigorous default for `dim`; < 0 otherwise: certification off
+    // per-stage HIP events (vr_index_set_search_profile): convert | thresholds | sweep | merge | exact pass
+    bool prof_on = false;
+    hipEvent_t prof_ev[SEARCH_PROF_EVENTS] = {};
+    double prof_ms[SEARCH_PROF_EVENTS - 1] = {};
+    int64_t prof_calls = 0;
 };
 
 extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_index_t* out) {
@@ -962,7 +972,8 @@ extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_
     const int64_t cp = pad256l(capacity);
     int r = ix->f32.alloc((size_t)cp * dim * 4);
     if (r == VR_OK) r = ix->bf16.alloc((size_t)cp * dim * 2);
-    if (r != VR_OK) { ix->f32.free(); ix->bf16.free(); delete ix; return r; }
+    if (r == VR_OK) r = ix->cert.alloc(64);
+    if (r != VR_OK) { ix->f32.free(); ix->bf16.free(); ix->cert.free(); delete ix; return r; }
     *out = ix;
     return VR_OK;
 }
@@ -971,13 +982,19 @@ extern "C" int vr_index_destroy(vr_index_t ix) {
     if (!ix) return VR_OK;
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->ck, &ix->os, &ix->oi, &ix->thr, &ix->sbuf}) b->free();
+    for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->ck, &ix->os, &ix->oi, &ix->ok, &ix->thr,
+                      &ix->sbuf, &ix->cert, &ix->flags})
+        b->free();
+    for (hipEvent_t e : ix->prof_ev) if (e) (void)hipEventDestroy(e);
     delete ix;
     return VR_OK;
 }
 
 extern "C" int vr_index_reset(vr_index_t ix) {
     if (!ix) return fail(VR_ERR_INVALID, "NULL index");
+    VRCHK(set_dev(ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(ix->cert.p, 0, 4));          // largest row norm
     ix->n = 0;
     return VR_OK;
 }
@@ -997,89 +1014,181 @@ extern "C" int vr_index_add(vr_index_t ix, const float* reps, int64_t n, int32_t
     float* dst = ix->f32.as<float>() + (size_t)ix->n * ix->dim;
     HIPCHK(hipMemcpyAsync(dst, reps, (size_t)n * ix->dim * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     HIPCHK(launch_f32_to_bf16(dst, (char*)ix->bf16.p + (size_t)ix->n * ix->dim * 2, (size_t)n * ix->dim, s));
+    HIPCHK(launch_row_norm_max(dst, n, ix->dim, ix->cert.as<float>(), s));      // |d| of the search's error bound
     if (!on_device) HIPCHK(hipStreamSynchronize(s));
     ix->n += n;
     return VR_OK;
 }
 
-extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k, float* out_scores,
-                               int64_t* out_ids, int32_t on_device, void* stream) {
-    if (!ix || !queries || !out_scores || !out_ids || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
+extern "C" int vr_index_set_search_eps(vr_index_t ix, float eps_rel) {
+    if (!ix) return fail(VR_ERR_INVALID, "NULL index");
+    if (eps_rel != eps_rel) ix->eps_rel = -2.f;    // NaN: back to the default bound
+    else ix->eps_rel = eps_rel < 0.f ? -1.f : eps_rel;
+    return VR_OK;
+}
+
+extern "C" int vr_index_search_stats(vr_index_t ix, int64_t* out4, int32_t reset) {
+    if (!ix || !out4) return fail(VR_ERR_INVALID, "NULL argument");
+    VRCHK(set_dev(ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned w[4];
+    HIPCHK(hipMemcpy(w, ix->cert.as<unsigned>() + 2, 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out4[i] = w[i];
+    if (reset) HIPCHK(hipMemset(ix->cert.as<unsigned>() + 2, 0, 16));
+    return VR_OK;
+}
+
+extern "C" int vr_index_set_search_profile(vr_index_t ix, int32_t enable) {
+    if (!ix) return fail(VR_ERR_INVALID, "NULL index");
+    VRCHK(set_dev(ix->device));
+    if (enable)
+        for (hipEvent_t& e : ix->prof_ev) if (!e) HIPCHK(hipEventCreate(&e));
+    ix->prof_on = enable != 0;
+    for (double& m : ix->prof_ms) m = 0;
+    ix->prof_calls = 0;
+    return VR_OK;
+}
+
+extern "C" int vr_index_get_search_profile(vr_index_t ix, double* ms5, int64_t* calls) {
+    if (!ix || !ms5 || !calls) return fail(VR_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < SEARCH_PROF_EVENTS - 1; ++i) ms5[i] = ix->prof_ms[i];
+    *calls = ix->prof_calls;
+    return VR_OK;
+}
+
+// queries [nq][dim] -> top k per query, as (scores, ids) or as packed keys with `id_offset` added to the row ids
+static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t k, float* out_scores, int64_t* out_ids,
+                       unsigned long long* out_keys, int64_t id_offset, int32_t on_device, void* stream) {
+    const bool keys_out = out_keys != nullptr;
+    if (!ix || !queries || nq <= 0 || (!keys_out && (!out_scores || !out_ids))) return fail(VR_ERR_INVALID, "bad arguments");
     const bool bigk = k > 26;             // deep retrieval: GEMM + radix select (search_bigk.hip)
     if (k <= 0 || k > search_bigk_max()) return fail(VR_ERR_INVALID, "k=%d unsupported (1..%d)", k, search_bigk_max());
+    if (keys_out && (id_offset < 0 || id_offset + ix->n >= ((int64_t)1 << 32) - 1))
+        return fail(VR_ERR_INVALID, "id_offset %lld + %lld rows do not fit 32-bit global ids", (long long)id_offset, (long long)ix->n);
     const int kp = bigk ? 0 : search_kprime(k);
     VRCHK(set_dev(ix->device));
     hipStream_t s = (hipStream_t)stream;
     const int dim = ix->dim;
-    const int64_t nqp = pad256l(nq);
+    const int64_t ldS = pad256l(std::max<int64_t>(ix->n, 1));
+    // queries per pass: the exact pass reserves one fp32 score row per query of a pass (1 GiB at most)
+    int64_t qblk = bigk ? 256 : std::max<int64_t>(256, ((int64_t)1 << 28) / ldS / 256 * 256);
+    qblk = std::min<int64_t>(qblk, pad256l(nq));
+    const int64_t nqp = pad256l(std::min<int64_t>(nq, qblk));
     if (ix->qcap < nqp) {
-        VRCHK(ix->q32.alloc((size_t)nqp * dim * 4));
         VRCHK(ix->qbf.alloc((size_t)nqp * dim * 2));
         VRCHK(ix->thr.alloc((size_t)nqp * 4));
         ix->qcap = nqp;
     }
     const float* q32 = queries;
     if (!on_device) {
+        VRCHK(ix->q32.reserve((size_t)nq * dim * 4));
         HIPCHK(hipMemcpyAsync(ix->q32.p, queries, (size_t)nq * dim * 4, hipMemcpyHostToDevice, s));
         q32 = ix->q32.as<float>();
     }
-    HIPCHK(launch_f32_to_bf16_pad(q32, ix->qbf.p, (size_t)nq * dim, (size_t)nqp * dim, s));   // rows >= nq: zeros
-    float* os = out_scores; int64_t* oi = out_ids;
+    float* os = out_scores; int64_t* oi = out_ids; unsigned long long* ok = out_keys;
     if (!on_device) {
-        VRCHK(ix->os.alloc((size_t)nq * k * 4));
-        VRCHK(ix->oi.alloc((size_t)nq * k * 8));
-        os = ix->os.as<float>(); oi = ix->oi.as<int64_t>();
+        if (keys_out) { VRCHK(ix->ok.reserve((size_t)nq * k * 8)); ok = ix->ok.as<unsigned long long>(); }
+        else {
+            VRCHK(ix->os.reserve((size_t)nq * k * 4));
+            VRCHK(ix->oi.reserve((size_t)nq * k * 8));
+            os = ix->os.as<float>(); oi = ix->oi.as<int64_t>();
+        }
     }
     if (ix->n == 0) {
-        std::vector<float> sc((size_t)nq * k, -INFINITY);
-        std::vector<int64_t> id((size_t)nq * k, -1);
-        HIPCHK(hipMemcpyAsync(os, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(oi, id.data(), id.size() * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (keys_out) HIPCHK(hipMemsetAsync(ok, 0, (size_t)nq * k * 8, s));
+        else {
+            std::vector<float> sc((size_t)nq * k, -INFINITY);
+            std::vector<int64_t> id((size_t)nq * k, -1);
+            HIPCHK(hipMemcpyAsync(os, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(oi, id.data(), id.size() * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
     } else {
-        SearchArgs a{};
-        a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
-        a.q_bf16 = ix->qbf.p; a.q_f32 = q32; a.nq = nq; a.k = k;
-        if (bigk) {
-            // score rows of <= 256 queries at a time: S[q][doc] = queries x index^T on the bf16 MFMA GEMM
-            constexpr int QB = 256;
-            const int64_t ldS = pad256l(ix->n);
-            if (ix->scap < QB * ldS) { VRCHK(ix->sbuf.alloc((size_t)QB * ldS * 4)); ix->scap = QB * ldS; }
-            a.out_scores = os; a.out_ids = oi;
-            for (int q0 = 0; q0 < nq; q0 += QB) {
-                const int nb = std::min(QB, nq - q0);
+        if (ix->fcap < nqp) { VRCHK(ix->flags.alloc((size_t)nqp * 4)); ix->fcap = nqp; }
+        VRCHK(ix->sbuf.reserve((size_t)nqp * ldS * 4));
+        for (int64_t q0 = 0; q0 < nq; q0 += qblk) {
+            const int nb = (int)std::min<int64_t>(qblk, nq - q0);
+            const int64_t nbp = pad256l(nb);
+            const bool prof = ix->prof_on && !bigk;
+            if (prof) HIPCHK(hipEventRecord(ix->prof_ev[0], s));
+            // rows >= nb: zeros; also clears the flag counter
+            HIPCHK(launch_f32_to_bf16_pad(q32 + (size_t)q0 * dim, ix->qbf.p, (size_t)nb * dim, (size_t)nbp * dim, s,
+                                          ix->cert.as<int>() + 1));
+            if (prof) HIPCHK(hipEventRecord(ix->prof_ev[1], s));
+            SearchArgs a{};
+            a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
+            a.q_bf16 = ix->qbf.p; a.q_f32 = q32 + (size_t)q0 * dim; a.nq = nb; a.k = k;
+            a.eps_rel = ix->eps_rel == -2.f ? search_default_eps_rel(dim) : ix->eps_rel;
+            a.dmax = ix->cert.as<float>();
+            a.flag_count = ix->cert.as<int>() + 1; a.flag_list = ix->flags.as<int>();
+            a.stats = ix->cert.as<unsigned>() + 2;
+            if (keys_out) { a.out_keys = ok + (size_t)q0 * k; a.id_offset = id_offset; }
+            else { a.out_scores = os + (size_t)q0 * k; a.out_ids = oi + (size_t)q0 * k; }
+            a.prof_ev = prof ? ix->prof_ev : nullptr;
+            if (bigk) {
+                // score rows of <= 256 queries at a time: S[q][doc] = queries x index^T on the bf16 MFMA GEMM
                 GemmArgs g{};
-                g.A = (const char*)ix->qbf.p + (size_t)q0 * dim * 2; g.lda = dim;
+                g.A = ix->qbf.p; g.lda = dim;
                 g.W = ix->bf16.p; g.ldw = dim; g.M = nb; g.N = (int)pad128l(ix->n); g.K = dim;
                 g.out = ix->sbuf.p; g.ldo = (int)ldS; g.alpha = 1.0f;
                 HIPCHK(launch_gemm(g, EPI_F32, GEMM_VARIANT_AUTO, s));
-                HIPCHK(launch_search_bigk(a, ix->sbuf.as<float>(), (size_t)ldS, q0, nb, s));
+                HIPCHK(launch_search_bigk(a, ix->sbuf.as<float>(), (size_t)ldS, 0, nb, s));
+            } else {
+                a.n_chunks = search_uses_stream(nb, dim) ? search_stream_chunks() : search_num_chunks(ix->n, nb);
+                a.thr_init = ix->thr.as<float>();
+                const int64_t need = std::max<int64_t>(nbp * a.n_chunks * kp, nbp * search_prepass_floats());
+                if (ix->ccap < need) {
+                    VRCHK(ix->cs.alloc((size_t)need * 4));
+                    VRCHK(ix->ci.alloc((size_t)need * 4));
+                    ix->ccap = need;
+                }
+                a.cand_scores = ix->cs.as<float>(); a.cand_ids = ix->ci.as<int>();
+                if (search_uses_256(nb)) {
+                    const int64_t kneed = nbp * a.n_chunks * 128;      // [q][chunk][2 halves][64]
+                    if (ix->kcap < kneed) { VRCHK(ix->ck.alloc((size_t)kneed * 8)); ix->kcap = kneed; }
+                    a.cand_keys = ix->ck.as<unsigned long long>();
+                }
+                HIPCHK(launch_search(a, s));
             }
-        } else {
-        a.n_chunks = search_uses_stream(nq, dim) ? search_stream_chunks() : search_num_chunks(ix->n, nq);
-        a.thr_init = ix->thr.as<float>();
-        const int64_t need = std::max<int64_t>(nqp * a.n_chunks * kp, nqp * search_prepass_floats());
-        if (ix->ccap < need) {
-            VRCHK(ix->cs.alloc((size_t)need * 4));
-            VRCHK(ix->ci.alloc((size_t)need * 4));
-            ix->ccap = need;
-        }
-        a.cand_scores = ix->cs.as<float>(); a.cand_ids = ix->ci.as<int>();
-        if (search_uses_256(nq)) {
-            const int64_t kneed = nqp * a.n_chunks * 128;      // [q][chunk][2 halves][64]
-            if (ix->kcap < kneed) { VRCHK(ix->ck.alloc((size_t)kneed * 8)); ix->kcap = kneed; }
-            a.cand_keys = ix->ck.as<unsigned long long>();
-        }
-        a.out_scores = os; a.out_ids = oi;
-        HIPCHK(launch_search(a, s));
+            if (prof) HIPCHK(hipEventRecord(ix->prof_ev[4], s));
+            if (a.eps_rel >= 0.f) {
+                // the exact fp32 pass over whatever the merge flagged (nothing, normally: both kernels leave at once)
+                HIPCHK(launch_exact_scores(a.index_f32, a.n_docs, dim, a.q_f32, a.flag_list, a.flag_count, ix->sbuf.as<float>(),
+                                           (size_t)ldS, s));
+                HIPCHK(launch_exact_select(a, ix->sbuf.as<float>(), (size_t)ldS, nb, s));
+            }
+            if (prof) {
+                HIPCHK(hipEventRecord(ix->prof_ev[5], s));
+                HIPCHK(hipEventSynchronize(ix->prof_ev[5]));
+                for (int i = 0; i + 1 < SEARCH_PROF_EVENTS; ++i) {
+                    float ms = 0.f;
+                    HIPCHK(hipEventElapsedTime(&ms, ix->prof_ev[i], ix->prof_ev[i + 1]));
+                    ix->prof_ms[i] += ms;
+                }
+                ix->prof_calls += 1;
+            }
         }
     }
     if (!on_device) {
-        HIPCHK(hipMemcpyAsync(out_scores, os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(out_ids, oi, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        if (keys_out) HIPCHK(hipMemcpyAsync(out_keys, ok, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        else {
+            HIPCHK(hipMemcpyAsync(out_scores, os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(out_ids, oi, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(hipStreamSynchronize(s));
     }
     return VR_OK;
+}
+
+extern "C" int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k, float* out_scores,
+                               int64_t* out_ids, int32_t on_device, void* stream) {
+    return search_impl(ix, queries, nq, k, out_scores, out_ids, nullptr, 0, on_device, stream);
+}
+
+extern "C" int vr_index_search_keys(vr_index_t ix, const float* queries, int32_t nq, int32_t k, int64_t id_offset,
+                                    uint64_t* out_keys, int32_t on_device, void* stream) {
+    if (!out_keys) return fail(VR_ERR_INVALID, "out_keys is NULL");
+    return search_impl(ix, queries, nq, k, nullptr, nullptr, (unsigned long long*)out_keys, id_offset, on_device, stream);
 }
 
 extern "C" int vr_topk_merge(int device_id, const float* scores, const int64_t* ids, int32_t n_parts, int32_t nq,
@@ -1087,6 +1196,14 @@ extern "C" int vr_topk_merge(int device_id, const float* scores, const int64_t* 
     if (!scores || !ids || !out_scores || !out_ids || n_parts <= 0 || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
     VRCHK(set_dev(device_id));
     HIPCHK(launch_topk_merge(scores, ids, n_parts, nq, k, out_scores, out_ids, (hipStream_t)stream));
+    return VR_OK;
+}
+
+extern "C" int vr_topk_merge_keys(int device_id, const uint64_t* keys, int32_t n_parts, int32_t nq, int32_t k,
+                                  float* out_scores, int64_t* out_ids, void* stream) {
+    if (!keys || !out_scores || !out_ids || n_parts <= 0 || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
+    VRCHK(set_dev(device_id));
+    HIPCHK(launch_topk_merge_keys((const unsigned long long*)keys, n_parts, nq, k, out_scores, out_ids, (hipStream_t)stream));
     return VR_OK;
 }
 

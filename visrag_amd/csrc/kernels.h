@@ -128,7 +128,8 @@ hipError_t launch_embed_gather(const int* ids, int T, const void* table, int dim
 hipError_t launch_pool(const float* h, const int* seq_offsets, int B, int dim, const float* norm_w,
                        float eps, float* out, float* tap_hidden, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
-hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s);   // + zero tail
+hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s,
+                                  int* zero_word = nullptr);   // + zero tail (+ one int cleared)
 // split x (f32) into hi + lo bf16 parts (x ~= hi + lo to ~16 bits of mantissa)
 hipError_t launch_split_bf16(const float* in, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t launch_iota_pos(const int* seq_offsets, int B, int* pos, hipStream_t s);
@@ -156,7 +157,17 @@ struct SearchArgs {
     float* out_scores; int64_t* out_ids;               // [nq][k]
     float* thr_init;                                   // workspace [nq_pad] or null (no pre-pass)
     unsigned long long* cand_keys;                     // 256-tile sweep scratch [nq_pad256][n_chunks][2][64] or null
+    // ---- certification of the candidate selection (search_common.h: certify_tail)
+    const float* thr_used;           // thresholds the sweep STARTED from (set by the launcher; null: none)
+    float eps_rel;                   // |bf16-MFMA score - fp32 score| <= eps_rel * |q| * dmax; < 0: no certification
+    const float* dmax;               // device scalar: largest row norm of the index
+    int* flag_count; int* flag_list; // queries whose top-k could not be certified: the exact fp32 pass redoes them
+    unsigned* stats;                 // [0] certified at once [1] after extended re-scoring [2] flagged [3] uncertified mode
+    // ---- packed output (multi-GPU exchange format): key = orderable(score) << 32 | ~(row + id_offset); 0 = none
+    unsigned long long* out_keys; int64_t id_offset;   // when set, out_scores / out_ids are not written
+    hipEvent_t* prof_ev;             // optional [SEARCH_PROF_EVENTS] stage marks recorded on the launch stream
 };
+constexpr int SEARCH_PROF_EVENTS = 6;   // start | queries converted | thresholds | sweep | merge | exact pass
 int search_kprime(int k);            // candidates kept per (query, chunk); 0 if k unsupported
 int search_num_chunks(int64_t n_docs, int nq);
 int search_prepass_floats();         // floats of cand_scores per (padded) query the threshold pre-pass needs
@@ -176,5 +187,18 @@ hipError_t launch_topk_merge_big(const float* scores, const int64_t* ids, int n_
                                  float* out_scores, int64_t* out_ids, hipStream_t s);   // n_parts * k <= 8192
 hipError_t launch_topk_merge(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t s);
+// the same merge over packed keys [n_parts][nq][k] (SearchArgs::out_keys format; ids are global already)
+hipError_t launch_topk_merge_keys(const unsigned long long* keys, int n_parts, int nq, int k, float* out_scores,
+                                  int64_t* out_ids, hipStream_t s);      // n_parts * k <= 8192
+// ---- exact fp32 pass for the flagged queries (search_exact.hip)
+// S[slot][doc] = fp32 dot(query flag_list[slot], row doc) for slot < *flag_count, in the summation order of the
+// re-scoring (search_common.h: dot_lane) — every workgroup leaves at once when nothing is flagged
+hipError_t launch_exact_scores(const float* index_f32, int64_t n_docs, int dim, const float* q_f32, const int* flag_list,
+                               const int* flag_count, float* S, size_t ldS, hipStream_t s);
+// top-k of the flagged queries from their exact score rows (radix select + re-score + sort): overwrites their outputs
+hipError_t launch_exact_select(const SearchArgs& a, const float* S, size_t ldS, int max_flagged, hipStream_t s);
+// dmax = max(dmax, |row|) over n rows (vr_index_add)
+hipError_t launch_row_norm_max(const float* rows, int64_t n, int dim, float* dmax, hipStream_t s);
+float search_default_eps_rel(int dim);
 
 }  // namespace vr

@@ -133,7 +133,9 @@ hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t 
 
 // f32 -> bf16 of the first n elements, zeros up to n_total (query rows + their padding in one launch;
 // n and n_total multiples of 4)
-__global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n, size_t n_total) {
+__global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n, size_t n_total,
+                                       int* __restrict__ zero_word) {
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;       // (the search's flag counter: saves a memset launch)
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (; i < n_total; i += stride) {
@@ -147,11 +149,11 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, bf16_t* __r
     }
 }
 
-hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s) {
+hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s, int* zero_word) {
     if (n_total == 0) return hipSuccess;
     if ((n | n_total) & 3) return hipErrorInvalidValue;
     const int blocks = (int)min((size_t)2048, (n_total / 4 + 255) / 256);
-    hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(blocks), dim3(256), 0, s, in, (bf16_t*)out, n, n_total);
+    hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(blocks), dim3(256), 0, s, in, (bf16_t*)out, n, n_total, zero_word);
     return hipGetLastError();
 }
 

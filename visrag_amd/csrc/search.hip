@@ -9,10 +9,12 @@
 //          passes 32 entries is compacted by ONE wave with a 64-lane bitonic sort on
 //          (score desc, doc id asc) keys — one candidate per lane, cross-lane exchange only.
 //          Result: the exact bf16-score top-KP of the chunk per query.
-//  merge   one wave per query: bitonic-merge the per-chunk lists to the global bf16 top-KP,
-//          re-score those KP rows against the fp32 index in fp32 (exact dot products), sort,
-//          emit the top k.  KP >= k + 6, so bf16 rounding (|err| ~ 6e-5 on unit vectors) cannot
-//          push a true top-k row out of the candidate set unless > 6 rows tie within it.
+//  merge   one workgroup per query: the per-chunk lists -> the best gathered bf16 candidates, the
+//          top KP re-scored against the fp32 index (exact fp32 dot products), then CERTIFIED
+//          (search_common.h: certify_tail): every further candidate whose bf16 score could still
+//          reach the fp32 top-k under the bf16 error bound is re-scored too, and a query whose
+//          lists cannot prove completeness goes to the exact fp32 pass (search_exact.hip).  The
+//          ids returned are the fp32 ranking's, not a tolerance-equivalent of it.
 // Block placement: the 8 query tiles of a chunk are consecutive on ONE XCD (b % 8 == chunk % 8)
 // so the index tile is fetched from HBM once and re-read from that XCD's L2.
 // Roofline: MFMA for Nq >~ 300 (2*Nq*Nd*D flop), HBM for small Nq (Nd*D*2 bytes per sweep).
@@ -183,100 +185,49 @@ __global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict
 }
 
 
-template <int KP>
-__global__ __launch_bounds__(256) void search_merge_kernel(SearchArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= p.nq) return;
-    const int wave = threadIdx.x >> 6;
-    const int total = p.n_chunks * KP;
-    const float* cs = p.cand_scores + (size_t)q * total;
-    const int* ci = p.cand_ids + (size_t)q * total;
-    // 1. lower bound of the global KP-th best key from the chunk HEADS (every chunk list is sorted,
-    //    valid entries first): lane-local max over its chunks, one sort, KP-th largest.  At least
-    //    KP distinct entries are >= it; KEY_NONE (fewer than KP non-empty lanes) keeps everything.
-    uint64_t head = KEY_NONE;
-    for (int c = lane; c < p.n_chunks; c += 64) {
-        const int id = ci[c * KP];
-        if (id >= 0) { const uint64_t key = make_key(cs[c * KP], (uint32_t)id); head = key > head ? key : head; }
-    }
-    const uint64_t thr = shfl_u64(wave_sort_desc(head), KP - 1);
-    // 2. walk the lists (lane = chunk) while they stay >= thr, appending survivors to LDS
-    __shared__ uint64_t surv[4][MERGE_CAP];
-    int n = 0;
-    for (int c0 = 0; c0 < p.n_chunks; c0 += 64) {
-        const int c = c0 + lane;
-        bool live = c < p.n_chunks;
-        for (int s = 0; s < KP; ++s) {
-            uint64_t key = KEY_NONE;
-            if (live) {
-                const int id = ci[c * KP + s];
-                if (id >= 0) key = make_key(cs[c * KP + s], (uint32_t)id);
-                live = key != KEY_NONE && key >= thr;
-            }
-            const unsigned long long bal = __ballot(live);
-            if (!bal) break;
-            if (live) {
-                const int pos = n + __popcll(bal & ((1ull << lane) - 1));
-                if (pos < MERGE_CAP) surv[wave][pos] = key;
-            }
-            n += __popcll(bal);
-        }
-    }
-    uint64_t best = KEY_NONE;
-    if (n <= MERGE_CAP) {
-        // 3. usually <= 64 survivors: one sort
-        for (int base = 0; base < n; base += 64) {
-            const uint64_t key = (base + lane < n) ? surv[wave][base + lane] : KEY_NONE;
-            best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
-        }
-    } else {
-        // massive ties at the threshold: merge every entry
-        for (int base = 0; base < total; base += 64) {
-            const int e = base + lane;
-            uint64_t key = KEY_NONE;
-            if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
-            best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
-        }
-    }
-    rescore_emit<KP>(p, q, best, lane);
-}
-
-// ---- merge for FEW queries: one workgroup per query ------------------------------------------
-// With a handful of queries the wave-per-query merge above is a latency chain on a mostly idle
-// chip (512 chunk lists -> 77 us for one query).  Here 256 threads read all chunk entries with
-// independent loads, bound the KP-th best from the chunk heads, filter,
-// and the four waves re-score the KP candidates in parallel.
+// ---- merge of the sorted chunk lists (128-tile sweep, streaming kernel): one workgroup per query ----
+// 256 threads read all chunk entries with independent loads, bound the GD-th best from the chunk
+// heads (GD = KP + 16: the certification below may want candidates past the KP-th), filter, sort the
+// survivors once, and the four waves re-score in parallel (certify_tail).
+// What the lists do NOT hold: a full list (KP entries) may have dropped rows below its last entry —
+// dropB is the largest such last entry; a shorter list holds every row of its chunk that passed the
+// sweep's starting threshold.
 template <int KP>
 __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
+    constexpr int GD = KP + 16 < 64 ? KP + 16 : 64;
     __shared__ uint64_t lm[256];
     __shared__ uint64_t surv[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];
     __shared__ uint64_t thr_s;
-    __shared__ int n_s;
+    __shared__ unsigned drop_s;
+    __shared__ int n_s, x_s;
+    __shared__ float tau_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int total = p.n_chunks * KP;
     const float* cs = p.cand_scores + (size_t)q * total;
     const int* ci = p.cand_ids + (size_t)q * total;
     // bound from the chunk HEADS (lists are sorted, so a head is its chunk's best): thread-local max
-    // over its chunks; the KP-th largest of the 64 folded maxima is <= KP distinct heads.  (Folding
+    // over its chunks; the GD-th largest of the 64 folded maxima is <= GD distinct heads.  (Folding
     // arbitrary entries instead mixes list positions and gives a far looser bound.)
     uint64_t m = KEY_NONE;
+    unsigned drop = 0u;                                  // orderable score of the best LAST entry of a full list
+    if (tid == 0) drop_s = 0u;
     for (int c = tid; c < p.n_chunks; c += 256) {
         const int id = ci[c * KP];
         const float sc = cs[c * KP];
         const uint64_t key = id >= 0 ? make_key(sc, (uint32_t)id) : KEY_NONE;
         m = key > m ? key : m;
+        if (ci[c * KP + KP - 1] >= 0) drop = max(drop, f32_orderable(cs[c * KP + KP - 1]));
     }
     lm[tid] = m;
-    if (tid < 64) exact_s[tid] = KEY_NONE;
     __syncthreads();
+    if (drop) atomicMax(&drop_s, drop);
     if (wave == 0) {
         uint64_t v = lm[lane];
 #pragma unroll
         for (int w = 1; w < 4; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
-        const uint64_t t = shfl_u64(wave_sort_desc(v), KP - 1);
+        const uint64_t t = shfl_u64(wave_sort_desc(v), GD - 1);
         if (lane == 0) { thr_s = t; n_s = 0; }
     }
     __syncthreads();
@@ -299,8 +250,8 @@ __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
         }
     }
     __syncthreads();
+    const int n = n_s;
     if (wave == 0) {
-        const int n = n_s;
         uint64_t best = KEY_NONE;
         if (n <= MERGE_CAP) {
             for (int base = 0; base < n; base += 64) {
@@ -318,41 +269,11 @@ __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
         cand[lane] = best;
     }
     __syncthreads();
-    // exact fp32 re-scoring, one candidate per wave at a time (same summation order as rescore_emit)
-    const int nv = p.dim >> 2;
-    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
-    f32x4 qv[MERGE_MAXV];
-#pragma unroll
-    for (int i = 0; i < MERGE_MAXV; ++i) {
-        const int c = lane + i * 64;
-        qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int c = wave; c < KP; c += 4) {
-        const uint64_t key = cand[c];
-        if (key == KEY_NONE) continue;                  // wave-uniform
-        const uint32_t id = ~(uint32_t)key;
-        const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id * p.dim);
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < MERGE_MAXV; ++i) {
-            const int cc = lane + i * 64;
-            if (cc < nv) {
-                const f32x4 d = dr[cc];
-                a += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
-            }
-        }
-        a = wave_sum(a);
-        if (lane == 0) exact_s[c] = make_key(a, id);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const uint64_t ex = wave_sort_desc(exact_s[lane]);
-        if (lane < p.k) {
-            const bool ok = ex != KEY_NONE;
-            p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(ex >> 32)) : -INFINITY;
-            p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)ex) : (int64_t)-1;
-        }
-    }
+    // entries outside `cand`: below the gather bound, or (more than 64 gathered) below cand[63]
+    const float coverB = n > 64 ? key_score(cand[63]) : (thr == KEY_NONE ? -INFINITY : key_score(thr));
+    float dropB = drop_s ? orderable_f32(drop_s) : -INFINITY;
+    if (p.thr_used) dropB = fmaxf(dropB, p.thr_used[q]);
+    certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s);
 }
 
 int search_kprime(int k) {
@@ -414,7 +335,10 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         if ((e = hipGetLastError()) != hipSuccess) return e;
         thr = a.thr_init;
     }
-    if (search_uses_256(a.nq)) return launch_sweep256(a, KP, thr, s);       // sweep + its own merge
+    if (a.prof_ev && (e = hipEventRecord(a.prof_ev[2], s)) != hipSuccess) return e;
+    SearchArgs am = a;
+    am.thr_used = thr;                                                       // what the sweep's lists are complete down to
+    if (search_uses_256(a.nq)) return launch_sweep256(am, KP, thr, s);      // sweep + its own merge
     if (search_uses_stream(a.nq, a.dim)) {
         if ((e = launch_search_stream(a, KP, s)) != hipSuccess) return e;
     } else {
@@ -422,8 +346,8 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SWEEP_SMEM, s, a, q_tiles, tpc, 1, thr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (a.nq <= SMALL_NQ) hipLaunchKernelGGL(search_merge_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(search_merge_kernel<KP>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    if (a.prof_ev && (e = hipEventRecord(a.prof_ev[3], s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(search_merge_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, am);
     return hipGetLastError();
 }
 
@@ -437,9 +361,11 @@ hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
     }
 }
 
-// ---- multi-GPU: merge per-shard (score, global id) lists after the all-gather -----------------
+// ---- multi-GPU: merge per-shard lists after the all-gather ------------------------------------
+// input either (score, global id) pairs or packed keys (SearchArgs::out_keys format, global ids inside)
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores,
-                                                         const int64_t* __restrict__ ids, int n_parts,
+                                                         const int64_t* __restrict__ ids,
+                                                         const unsigned long long* __restrict__ keys, int n_parts,
                                                          int nq, int k, float* __restrict__ out_scores,
                                                          int64_t* __restrict__ out_ids) {
     const int lane = threadIdx.x & 63;
@@ -453,7 +379,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         if (e < total) {
             const int part = e / k, s = e % k;
             const size_t o = ((size_t)part * nq + q) * k + s;
-            if (ids[o] >= 0) key = make_key(scores[o], (uint32_t)ids[o]);
+            if (keys) key = keys[o];
+            else if (ids[o] >= 0) key = make_key(scores[o], (uint32_t)ids[o]);
         }
         best = (base == 0) ? wave_bitonic_desc(key, lane) : wave_merge_top64(best, key, lane);
     }
@@ -464,13 +391,26 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
     }
 }
 
+hipError_t launch_topk_merge_any(const float* scores, const int64_t* ids, const unsigned long long* keys, int n_parts,
+                                 int nq, int k, float* out_scores, int64_t* out_ids, hipStream_t s);   // search_bigk.hip
+
 hipError_t launch_topk_merge(const float* scores, const int64_t* ids, int n_parts, int nq, int k,
                              float* out_scores, int64_t* out_ids, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     if (k <= 0) return hipErrorInvalidValue;
-    if (k > 64) return launch_topk_merge_big(scores, ids, n_parts, nq, k, out_scores, out_ids, s);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, scores, ids, n_parts, nq, k,
-                       out_scores, out_ids);
+    if (k > 64) return launch_topk_merge_any(scores, ids, nullptr, n_parts, nq, k, out_scores, out_ids, s);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, scores, ids, (const unsigned long long*)nullptr,
+                       n_parts, nq, k, out_scores, out_ids);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_merge_keys(const unsigned long long* keys, int n_parts, int nq, int k, float* out_scores,
+                                  int64_t* out_ids, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    if (k <= 0) return hipErrorInvalidValue;
+    if (k > 64) return launch_topk_merge_any(nullptr, nullptr, keys, n_parts, nq, k, out_scores, out_ids, s);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, (const float*)nullptr, (const int64_t*)nullptr,
+                       keys, n_parts, nq, k, out_scores, out_ids);
     return hipGetLastError();
 }
 

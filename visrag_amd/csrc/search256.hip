@@ -30,6 +30,7 @@ namespace vr {
 
 constexpr int HL_CAP = 64;          // slots per half-list
 constexpr int HL_TRIG = 48;         // compact a half-list longer than this (a strip adds <= 16)
+constexpr int HL_COMPACTED = 0x100; // flag in a half-list's emitted length: it was compacted (rows were dropped from it)
 
 struct Sweep256Lds {
     float thr[256];
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
     // lengths of this wave's half-lists, replicated over the 16 lanes of a group:
     // byte r of c8[j] = length of the list of query wn*64 + j*16 + fq*4 + r
     uint32_t c8[4] = {0u, 0u, 0u, 0u};
+    uint32_t cmask = 0u;                 // bit j*4 + r: that half-list was compacted (merge: rows may be missing from it)
 
     // rare: a half-list of this wave passed HL_TRIG -> the wave alone sorts it, keeps the best KP and
     // raises the query's threshold.  A runtime loop over the 16 (j, r) columns (kept rolled: unrolled
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
                     const float t = orderable_f32((uint32_t)(key >> 32));
                     if (t > L.thr[qq]) L.thr[qq] = t;              // (the partner half may race: both bounds are valid)
                 }
-                if (fq_e == (src >> 4)) nw = (nw & ~(0xFFu << (8 * r))) | ((uint32_t)keep << (8 * r));
+                if (fq_e == (src >> 4)) { nw = (nw & ~(0xFFu << (8 * r))) | ((uint32_t)keep << (8 * r)); cmask |= 1u << jr; }
             }
             c8[0] = j == 0 ? nw : c8[0];
             c8[1] = j == 1 ? nw : c8[1];
@@ -232,7 +234,8 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qq = wn * 64 + j * 16 + fq * 4 + r;
-                p.cand_ids[((size_t)(q0 + qq) * p.n_chunks + chunk) * 2 + wm] = (int)((c8[j] >> (8 * r)) & 0xFFu);
+                p.cand_ids[((size_t)(q0 + qq) * p.n_chunks + chunk) * 2 + wm] =
+                    (int)((c8[j] >> (8 * r)) & 0xFFu) | (((cmask >> (j * 4 + r)) & 1u) ? HL_COMPACTED : 0);
             }
         }
     }
@@ -245,26 +248,32 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
 //     query's global KP-th best key (KEY_NONE when fewer than KP threads saw a key);
 //  2. entries >= that bound are appended to LDS (ballot compaction) — typically ~20 of ~1900;
 //  3. one sort (or, for > MERGE_CAP survivors = massive ties, a merge over everything);
-//  4. fp32 re-scoring by the four waves concurrently + final sort (rescore_emit).
+//  4. fp32 re-scoring by the four waves concurrently, certification, final sort (certify_tail).
 // All list walks of a query run in parallel: a wave-per-query merge left most of the chip idle
 // behind a chain of dependent loads with a few hundred queries (128 queries: 101 us).
 template <int KP>
 __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
+    constexpr int GD = KP + 16 < 64 ? KP + 16 : 64;   // gather depth: certification may want candidates past the KP-th
     __shared__ uint64_t lm[256];
     __shared__ uint64_t surv[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];
     __shared__ uint64_t thr_s;
-    __shared__ int n_s;
+    __shared__ int n_s, x_s, comp_s;
+    __shared__ float tau_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int lists = p.n_chunks * 2;
-    const int* cnts = p.cand_ids + (size_t)q * lists;
+    const int* cnts = p.cand_ids + (size_t)q * lists;      // length | HL_COMPACTED
     const unsigned long long* keys = p.cand_keys + (size_t)q * lists * HL_CAP;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
     uint64_t m = KEY_NONE;
+    int comp = 0;
+    if (tid == 0) comp_s = 0;
     for (int l = tid; l < lists; l += 256) {
-        const int c = cnts[l];
+        const int cw = cnts[l];
+        const int c = cw & 0xFF;
+        comp |= cw >> 8;
         const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)l * HL_CAP);
         for (int e = 0; e < c; e += 4) {
             const u64x2 a = row[e >> 1], b2 = row[(e >> 1) + 1];
@@ -276,19 +285,19 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
         }
     }
     lm[tid] = m;
-    if (tid < 64) exact_s[tid] = KEY_NONE;
     __syncthreads();
+    if (comp) atomicOr(&comp_s, 1);
     if (wave == 0) {
         uint64_t v = lm[lane];
 #pragma unroll
         for (int w = 1; w < 4; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
-        const uint64_t t = shfl_u64(wave_sort_desc(v), KP - 1);
+        const uint64_t t = shfl_u64(wave_sort_desc(v), GD - 1);
         if (lane == 0) { thr_s = t; n_s = 0; }
     }
     __syncthreads();
     const uint64_t thr = thr_s;
     for (int l = tid; l < lists; l += 256) {
-        const int c = cnts[l];
+        const int c = cnts[l] & 0xFF;
         const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)l * HL_CAP);
         for (int e = 0; e < c; e += 2) {
             const u64x2 a = row[e >> 1];
@@ -302,8 +311,8 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
         }
     }
     __syncthreads();
+    const int n = n_s;
     if (wave == 0) {
-        const int n = n_s;
         uint64_t best = KEY_NONE;
         if (n <= MERGE_CAP) {
             for (int base = 0; base < n; base += 64) {
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
             }
         } else {
             for (int l = 0; l < lists; ++l) {
-                const int c = cnts[l];
+                const int c = cnts[l] & 0xFF;
                 const uint64_t key = (lane < c) ? keys[(size_t)l * HL_CAP + lane] : KEY_NONE;
                 best = (l == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
             }
@@ -320,40 +329,14 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
         cand[lane] = best;
     }
     __syncthreads();
-    const int nv = p.dim >> 2;
-    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
-    f32x4 qv[MERGE_MAXV];
-#pragma unroll
-    for (int i = 0; i < MERGE_MAXV; ++i) {
-        const int c = lane + i * 64;
-        qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int c = wave; c < KP; c += 4) {
-        const uint64_t key = cand[c];
-        if (key == KEY_NONE) continue;                  // wave-uniform
-        const uint32_t id = ~(uint32_t)key;
-        const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id * p.dim);
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < MERGE_MAXV; ++i) {
-            const int cc = lane + i * 64;
-            if (cc < nv) {
-                const f32x4 d = dr[cc];
-                a += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
-            }
-        }
-        a = wave_sum(a);
-        if (lane == 0) exact_s[c] = make_key(a, id);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const uint64_t ex = wave_sort_desc(exact_s[lane]);
-        if (lane < p.k) {
-            const bool ok = ex != KEY_NONE;
-            p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(ex >> 32)) : -INFINITY;
-            p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)ex) : (int64_t)-1;
-        }
-    }
+    // what the re-scoring does not see (search_common.h: certify_tail):
+    //   list entries outside `cand`: below the gather bound, or (more than 64 gathered) below cand[63];
+    //   rows that never reached a list: below the sweep's starting threshold — or, where a half-list was compacted
+    //   (its chunk's threshold rose to that list's KP-th best, itself <= the global KP-th best), below cand[KP - 1]
+    const float coverB = n > 64 ? key_score(cand[63]) : (thr == KEY_NONE ? -INFINITY : key_score(thr));
+    float dropB = p.thr_used ? p.thr_used[q] : -INFINITY;
+    if (comp_s && cand[KP - 1] != KEY_NONE) dropB = fmaxf(dropB, key_score(cand[KP - 1]));
+    certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s);
 }
 
 template <int KP>
@@ -375,6 +358,7 @@ static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s)
         e = hipGetLastError();
     }
     if (e != hipSuccess) return e;
+    if (a.prof_ev && (e = hipEventRecord(a.prof_ev[3], s)) != hipSuccess) return e;
     hipLaunchKernelGGL(search_merge256_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, a);   // one workgroup per query
     return hipGetLastError();
 }

@@ -39,7 +39,7 @@ constexpr int SW_STAGE = 2 * G256_TILE_BYTES;      // A tile + W tile = 64 KiB
 constexpr unsigned SW_OOB = 0x80000000u;
 constexpr int SW_HL_CAP = 64;                      // slots per half-list (= search256.hip's)
 constexpr int SW_HL_TRIG = 48;                     // compact a half-list longer than this (a strip adds <= 16)
-constexpr int SW_SMEM = 2 * SW_STAGE + 256 * 4;    // stages + thresholds
+constexpr int SW_SMEM = 2 * SW_STAGE + 256 * 4 + 256;    // stages + thresholds + per-query "a list was compacted" bytes
 
 __device__ __forceinline__ uint64_t sw_ld_key(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -62,6 +62,7 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
     constexpr int NS = 64, NR = 16, DS = 5, SB1 = 40, D1 = 5, SB2 = 8;     // the schedule of gemm256w.hip, NJ = 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const thr_lds = reinterpret_cast<float*>(smem + 2 * SW_STAGE);
+    unsigned char* const comp_lds = reinterpret_cast<unsigned char*>(smem + 2 * SW_STAGE + 256 * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
 
@@ -80,6 +81,7 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
         float t0 = (thr_init && q0 + tid < p.nq) ? thr_init[q0 + tid] : -INFINITY;
         if (q0 + tid >= p.nq) t0 = INFINITY;                  // padding queries never collect candidates
         thr_lds[tid] = t0;
+        comp_lds[tid] = 0;
     }
     __syncthreads();
 
@@ -126,6 +128,7 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
                     if (t > thr_lds[qq]) thr_lds[qq] = t;          // (the partner half may race: both bounds are valid)
                 }
                 if (fq == (src >> 4)) nw = (nw & ~(0xFFu << (8 * r))) | ((uint32_t)keep << (8 * r));
+                if (lane == 0) comp_lds[qq] = 1;                   // rows were dropped from this query's lists: the merge must know
             }
             c8_set(j, nw);
         }
@@ -270,7 +273,8 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qq = wn * 128 + j * 16 + fq * 4 + r;
-                p.cand_ids[((size_t)(q0 + qq) * p.n_chunks + chunk) * 2 + wm] = (int)((c8[j] >> (8 * r)) & 0xFFu);
+                p.cand_ids[((size_t)(q0 + qq) * p.n_chunks + chunk) * 2 + wm] =
+                    (int)((c8[j] >> (8 * r)) & 0xFFu) | (comp_lds[qq] ? 0x100 : 0);   // 0x100 = search256.hip's HL_COMPACTED
             }
         }
     }

@@ -49,55 +49,127 @@ __device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fres
 constexpr int MERGE_MAXV = 10;     // dim <= 64 * 4 * MERGE_MAXV
 constexpr int MERGE_CAP = 256;     // survivor buffer per query (merge kernels)
 
-// Tail of both merge kernels: `best` holds the bf16-score top-KP keys of query q, sorted
-// descending (lane c = candidate c).  Re-score them against the fp32 index with exact fp32 dot
-// products (the ranking torch.topk over an fp32 matmul sees), sort on (score desc, id asc), emit
-// the top k.  Four candidates per round so that their row reads overlap (the rows are cold:
-// latency-, not bandwidth-bound).
-template <int KP>
-__device__ __forceinline__ void rescore_emit(const SearchArgs& p, int q, uint64_t best, int lane) {
-    const int nv = p.dim >> 2;
-    f32x4 qv[MERGE_MAXV];
-    const f32x4* qr = reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)q * p.dim);
+// ---- exact fp32 scores ------------------------------------------------------------------------
+// ONE definition of the fp32 dot product behind every score the library returns: lane l owns the
+// float4 chunks l, l + 64, ...; inside a chunk a fixed fma chain; wave_sum over the lanes last.
+// (Written with explicit fmaf so that the compiler's contraction choices cannot differ between the
+// kernels that use it: the merge kernels' re-scoring and the exact pass of search_exact.hip must
+// produce the SAME float for the same (query, row).)
+__device__ __forceinline__ float dot_chunk(const f32x4 q, const f32x4 d, float a) {
+    float t = q[0] * d[0];
+    t = __builtin_fmaf(q[1], d[1], t);
+    t = __builtin_fmaf(q[2], d[2], t);
+    t = __builtin_fmaf(q[3], d[3], t);
+    return a + t;
+}
+__device__ __forceinline__ void load_query_regs(f32x4 (&qv)[MERGE_MAXV], const float* q, int nv, int lane) {
+    const f32x4* qr = reinterpret_cast<const f32x4*>(q);
 #pragma unroll
     for (int i = 0; i < MERGE_MAXV; ++i) {
         const int c = lane + i * 64;
         qv[i] = (c < nv) ? qr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    uint64_t exact = KEY_NONE;
-    for (int c0 = 0; c0 < KP; c0 += 4) {
-        if (shfl_u64(best, c0) == KEY_NONE) break;       // wave-uniform; keys are sorted, NONE last
-        float s[4];
-        uint32_t id[4];
-        bool ok[4];
+}
+__device__ __forceinline__ float dot_lane(const f32x4 (&qv)[MERGE_MAXV], const float* row, int nv, int lane) {
+    const f32x4* dr = reinterpret_cast<const f32x4*>(row);
+    float a = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t key = shfl_u64(best, c0 + u);
-            ok[u] = key != KEY_NONE;
-            id[u] = ok[u] ? ~(uint32_t)key : 0u;        // row 0 is always readable
-            const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)id[u] * p.dim);
-            float a = 0.f;
+    for (int i = 0; i < MERGE_MAXV; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < nv) a = dot_chunk(qv[i], dr[cc], a);
+    }
+    return a;
+}
+
+__device__ __forceinline__ float key_score(uint64_t key) { return orderable_f32((uint32_t)(key >> 32)); }
+
+// slot `slot` of query q's result: (score, row id) or, for the multi-GPU exchange, the packed key with the
+// shard's id offset applied
+__device__ __forceinline__ void emit_slot(const SearchArgs& p, int q, int slot, uint64_t key) {
+    const bool ok = key != KEY_NONE;
+    const size_t o = (size_t)q * p.k + slot;
+    if (p.out_keys) {
+        const uint32_t gid = (uint32_t)((int64_t)(~(uint32_t)key) + p.id_offset);
+        p.out_keys[o] = ok ? ((key & 0xFFFFFFFF00000000ull) | (uint32_t)(~gid)) : KEY_NONE;
+    } else {
+        p.out_scores[o] = ok ? key_score(key) : -INFINITY;
+        p.out_ids[o] = ok ? (int64_t)(~(uint32_t)key) : (int64_t)-1;
+    }
+}
+
+// ---- certified candidate selection ------------------------------------------------------------
+// The sweeps rank rows by their bf16-MFMA score b(d); the library returns the ranking by the fp32 score
+// s(d).  With q^ = bf16(q), d^ = bf16(d) (round to nearest: relative error <= 2^-9 each) and fp32
+// accumulation of the exact bf16 products over dim terms,
+//     |b(d) - s(d)| <= (2^-8 + 2^-18 + (dim + 64) * 2^-23) * |q| * |d|  =  eps          (Cauchy-Schwarz)
+// (search_default_eps_rel; the caller may set a tighter model with vr_index_set_search_eps).  A row outside
+// the re-scored set R can only belong to the fp32 top-k if s(d) >= s_k (the k-th best fp32 score inside
+// R), i.e. if b(d) >= s_k - eps =: tau.  certify_tail therefore
+//   1. re-scores the bf16 top-KP, takes s_k and tau;
+//   2. re-scores every further gathered candidate with b >= tau (they are sorted: a prefix);
+//   3. certifies the result if everything NOT re-scored is known to lie below tau:
+//        coverB  >= b of every list entry that was not gathered into `cand`,
+//        dropB   >= b of every row the sweep dropped before it reached a list;
+//      otherwise the query goes on the flag list and the exact fp32 pass (search_exact.hip) redoes it.
+// cand: LDS[64], the best gathered keys sorted descending (KEY_NONE padded); exact_s: LDS[64] scratch.
+// Called by all 256 threads of the query's workgroup; cand / coverB / dropB must be visible (barrier).
+template <int KP>
+__device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
+                                             float coverB, float dropB, float* sh_tau, int* sh_x) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = p.dim >> 2;
+    const float* qrow = p.q_f32 + (size_t)q * p.dim;
+    f32x4 qv[MERGE_MAXV];
+    load_query_regs(qv, qrow, nv, lane);
+    auto rescore = [&](int c) {                          // wave-uniform c
+        const uint64_t key = cand[c];
+        if (key == KEY_NONE) return;
+        const uint32_t id = ~(uint32_t)key;
+        const float a = wave_sum(dot_lane(qv, p.index_f32 + (size_t)id * p.dim, nv, lane));
+        if (lane == 0) exact_s[c] = make_key(a, id);
+    };
+    if (tid < 64) exact_s[tid] = KEY_NONE;
+    __syncthreads();
+    for (int c = wave; c < KP; c += 4) rescore(c);
+    __syncthreads();
+    const bool certify = p.eps_rel >= 0.f;
+    if (wave == 0) {
+        float tau = -INFINITY;
+        int x = 0;
+        if (certify) {
+            float qq = 0.f;
 #pragma unroll
-            for (int i = 0; i < MERGE_MAXV; ++i) {
-                const int cc = lane + i * 64;
-                if (cc < nv) {
-                    const f32x4 d = dr[cc];
-                    a += qv[i][0] * d[0] + qv[i][1] * d[1] + qv[i][2] * d[2] + qv[i][3] * d[3];
+            for (int i = 0; i < MERGE_MAXV; ++i)
+                qq += qv[i][0] * qv[i][0] + qv[i][1] * qv[i][1] + qv[i][2] * qv[i][2] + qv[i][3] * qv[i][3];
+            const float eps = p.eps_rel * sqrtf(wave_sum(qq)) * p.dmax[0];
+            const uint64_t kth = shfl_u64(wave_sort_desc(exact_s[lane]), p.k - 1);
+            if (kth != KEY_NONE) tau = key_score(kth) - eps;
+            const uint64_t c = cand[lane];
+            x = __popcll(__ballot(lane >= KP && c != KEY_NONE && key_score(c) >= tau));
+        }
+        if (lane == 0) { *sh_tau = tau; *sh_x = x; }
+    }
+    __syncthreads();
+    const int x = *sh_x;
+    for (int c = KP + wave; c < KP + x; c += 4) rescore(c);
+    __syncthreads();
+    if (wave == 0) {
+        const uint64_t ex = wave_sort_desc(exact_s[lane]);
+        if (lane < p.k) emit_slot(p, q, lane, ex);
+        if (lane == 0) {
+            const float tau = *sh_tau;
+            int what = 3;
+            if (certify) {
+                const bool below_c = coverB == -INFINITY || coverB < tau;
+                const bool below_d = dropB == -INFINITY || dropB < tau;
+                what = (below_c && below_d) ? (x ? 1 : 0) : 2;
+                if (what == 2 && p.flag_count) {
+                    const int pos = atomicAdd(p.flag_count, 1);
+                    p.flag_list[pos] = q;
                 }
             }
-            s[u] = a;
+            if (p.stats) atomicAdd(&p.stats[what], 1u);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float t = wave_sum(s[u]);
-            if (ok[u] && lane == c0 + u) exact = make_key(t, id[u]);
-        }
-    }
-    exact = wave_sort_desc(exact);
-    if (lane < p.k) {
-        const bool ok = exact != KEY_NONE;
-        p.out_scores[(size_t)q * p.k + lane] = ok ? orderable_f32((uint32_t)(exact >> 32)) : -INFINITY;
-        p.out_ids[(size_t)q * p.k + lane] = ok ? (int64_t)(~(uint32_t)exact) : (int64_t)-1;
     }
 }
 

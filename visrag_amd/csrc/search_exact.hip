@@ -1,0 +1,119 @@
+// The exact fp32 pass behind vr_index_search's certification (search_common.h: certify_tail).
+//
+// The fused sweeps pick candidates by bf16-MFMA score and re-score them in fp32.  A query whose
+// candidate lists cannot PROVE that no row outside them reaches the fp32 top-k (more near-ties around
+// the k-th score than the lists hold, or a threshold that cut too high) is put on a flag list by its
+// merge workgroup.  This file redoes those queries from the fp32 index alone:
+//
+//   exact_scores_kernel   S[slot][row] = fp32 dot(query flag_list[slot], row) for every row of the
+//                         index, in the summation order of the re-scoring (dot_lane): a workgroup owns
+//                         64 rows; it keeps up to EX_QB flagged queries in LDS at a time and every wave
+//                         takes 16 of the rows, a row's float4 chunks in registers.
+//   bigk_select_kernel    (search_bigk.hip, exact mode) radix-selects the top k of each score row.
+//
+// Both launches are issued on EVERY search (the host cannot know the flag count without a
+// synchronisation) and leave at once when nothing is flagged — the normal case; cost ~2 launch slots.
+// Roofline when it does run: HBM (the fp32 index is read once per EX_QB flagged queries).
+//
+// Also here: the largest row norm of the index (vr_index_add), the |d| of the error bound.
+#include "kernels.h"
+#include "search_common.h"
+
+namespace vr {
+
+constexpr int EX_QB = 8;            // flagged queries resident in LDS per round (8 x dim x 4 B: 72 KiB at dim 2304)
+constexpr int EX_ROWS = 64;         // rows per workgroup
+
+__global__ __launch_bounds__(256) void exact_scores_kernel(const float* __restrict__ index_f32, int64_t n_docs, int dim,
+                                                           const float* __restrict__ q_f32,
+                                                           const int* __restrict__ flag_list,
+                                                           const int* __restrict__ flag_count, float* __restrict__ S,
+                                                           size_t ldS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nf = flag_count[0];
+    if (nf <= 0) return;
+    f32x4* qs = reinterpret_cast<f32x4*>(smem);                 // [EX_QB][nv]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = dim >> 2;
+    const int64_t row0 = (int64_t)blockIdx.x * EX_ROWS + wave * 16;
+    for (int f0 = 0; f0 < nf; f0 += EX_QB) {
+        const int nb = min(EX_QB, nf - f0);
+        __syncthreads();
+        for (int e = tid; e < nb * nv; e += 256) {
+            const int b = e / nv, c = e % nv;
+            qs[b * nv + c] = reinterpret_cast<const f32x4*>(q_f32 + (size_t)flag_list[f0 + b] * dim)[c];
+        }
+        __syncthreads();
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + r;
+            if (row >= n_docs) break;                             // wave-uniform
+            const f32x4* dr = reinterpret_cast<const f32x4*>(index_f32 + (size_t)row * dim);
+            f32x4 dv[MERGE_MAXV];
+#pragma unroll
+            for (int i = 0; i < MERGE_MAXV; ++i) {
+                const int c = lane + i * 64;
+                dv[i] = (c < nv) ? dr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int b = 0; b < nb; ++b) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < MERGE_MAXV; ++i) {
+                    const int c = lane + i * 64;
+                    if (c < nv) a = dot_chunk(qs[b * nv + c], dv[i], a);      // same chain as dot_lane(q, row)
+                }
+                a = wave_sum(a);
+                if (lane == 0) S[(size_t)(f0 + b) * ldS + row] = a;
+            }
+        }
+    }
+}
+
+hipError_t launch_exact_scores(const float* index_f32, int64_t n_docs, int dim, const float* q_f32, const int* flag_list,
+                               const int* flag_count, float* S, size_t ldS, hipStream_t s) {
+    if (n_docs <= 0) return hipSuccess;
+    if (dim % 4 || dim > 64 * 4 * MERGE_MAXV) return hipErrorInvalidValue;
+    const int lds = EX_QB * dim * 4;
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)exact_scores_kernel, EX_QB * 64 * 4 * MERGE_MAXV * 4, attr);
+    const int64_t blocks = (n_docs + EX_ROWS - 1) / EX_ROWS;
+    hipLaunchKernelGGL(exact_scores_kernel, dim3((unsigned)blocks), dim3(256), lds, s, index_f32, n_docs, dim, q_f32,
+                       flag_list, flag_count, S, ldS);
+    return hipGetLastError();
+}
+
+// ---- largest row norm ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norm_max_kernel(const float* __restrict__ rows, int64_t n, int dim,
+                                                           float* __restrict__ dmax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = dim >> 2;
+    float m = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        const f32x4* x = reinterpret_cast<const f32x4*>(rows + (size_t)r * dim);
+        float ss = 0.f;
+        for (int c = lane; c < nv; c += 64) {
+            const f32x4 v = x[c];
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        m = fmaxf(m, wave_sum(ss));
+    }
+    // norms are >= 0: their bit patterns order like unsigned integers.  Round the root up a little: a bound.
+    if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dmax), __float_as_uint(sqrtf(m) * 1.000001f));
+}
+
+hipError_t launch_row_norm_max(const float* rows, int64_t n, int dim, float* dmax, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (dim % 4) return hipErrorInvalidValue;
+    const int64_t nb4 = (n + 3) / 4;
+    const int blocks = (int)(nb4 < 2048 ? nb4 : 2048);
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3(blocks), dim3(256), 0, s, rows, n, dim, dmax);
+    return hipGetLastError();
+}
+
+// |bf16-MFMA score - fp32 score| <= eps_rel * |q| * |d| (search_common.h): both operands rounded to nearest bf16
+// (2^-9 each: 2^-8 + 2^-18 for the product), the exact products accumulated in fp32 over dim terms (<= 2^-23 per
+// add, allowing a truncating adder), and the fp32 re-scoring's own rounding on the other side
+float search_default_eps_rel(int dim) {
+    return 0x1p-8f + 0x1p-18f + (float)(2 * dim + 128) * 0x1p-24f;
+}
+
+}  // namespace vr

@@ -243,6 +243,59 @@ class HipIndex:
         return sc, ix
 
 
+    def search_keys(self, queries: torch.Tensor, k: int, id_offset: int = 0) -> torch.Tensor:
+        """The same search with each result packed into ONE 64-bit word (include/visrag_hip.h:
+        vr_index_search_keys): orderable(score) << 32 | ~(row + id_offset); 0 = empty slot.  -> int64 [nq, k]
+        on the queries' device — the buffer the ranks all-gather (retriever.sharded_search)."""
+        q = queries.to(torch.float32).contiguous()
+        if not q.is_cuda:
+            raise ValueError("search_keys works on device tensors (the exchange buffer lives in HBM)")
+        nq = q.shape[0]
+        keys = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        _lib.check(self.lib.vr_index_search_keys(self._h, C.c_void_p(q.data_ptr()), nq, k, int(id_offset),
+                                                 C.c_void_p(keys.data_ptr()), 1, C.c_void_p(_stream_ptr(self.device))),
+                   "vr_index_search_keys")
+        return keys
+
+    def set_search_eps(self, eps_rel: Optional[float]) -> None:
+        """Error model of the top-k certification: None = the rigorous default, < 0 = certification off."""
+        _lib.check(self.lib.vr_index_set_search_eps(self._h, float("nan") if eps_rel is None else float(eps_rel)))
+
+    def search_stats(self, reset: bool = False) -> Dict[str, int]:
+        out = (C.c_int64 * 4)()
+        _lib.check(self.lib.vr_index_search_stats(self._h, out, 1 if reset else 0))
+        return {"certified": int(out[0]), "certified_extended": int(out[1]), "exact_pass": int(out[2]),
+                "uncertified": int(out[3])}
+
+    SEARCH_STAGES = ("convert", "thresholds", "sweep", "merge", "exact_pass")
+
+    def set_search_profile(self, on: bool) -> None:
+        _lib.check(self.lib.vr_index_set_search_profile(self._h, 1 if on else 0))
+
+    def get_search_profile(self) -> Dict[str, float]:
+        ms, calls = (C.c_double * 5)(), C.c_int64()
+        _lib.check(self.lib.vr_index_get_search_profile(self._h, ms, C.byref(calls)))
+        n = max(int(calls.value), 1)
+        out = {name: ms[i] / n for i, name in enumerate(self.SEARCH_STAGES)}
+        out["calls"] = int(calls.value)
+        return out
+
+
+def topk_merge_keys(keys: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[n_parts, nq, k] packed keys (HipIndex.search_keys of every shard, e.g. the all-gather's output as it is)
+    -> merged (scores [nq, k] f32, global ids [nq, k] i64) on the device."""
+    _require_gpu()
+    lib = _lib.load()
+    n_parts, nq, k = keys.shape
+    keys = keys.contiguous()
+    os_ = torch.empty((nq, k), dtype=torch.float32, device=keys.device)
+    oi = torch.empty((nq, k), dtype=torch.int64, device=keys.device)
+    dev = keys.device.index or 0
+    _lib.check(lib.vr_topk_merge_keys(dev, C.c_void_p(keys.data_ptr()), n_parts, nq, k, C.c_void_p(os_.data_ptr()),
+                                      C.c_void_p(oi.data_ptr()), C.c_void_p(_stream_ptr(dev))), "vr_topk_merge_keys")
+    return os_, oi
+
+
 def topk_merge(scores: torch.Tensor, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """[n_parts, nq, k] per-shard (score, global id) lists -> merged [nq, k] (device tensors)."""
     _require_gpu()

@@ -11,8 +11,8 @@ global top-k (one search over the concatenated index: the fast path when only de
 evaluated).
 
 `sharded_search` is the MI355X multi-GPU path of BASELINE.json: corpus rows sharded across
-ranks, local top-k per rank, ONE RCCL all-gather of the packed [nq, k] (score, global id) words,
-on-device merge."""
+ranks, local top-k per rank emitted as packed 64-bit (score, global id) keys by the search's own
+merge kernel, ONE RCCL all-gather of those [nq, k] words, on-device merge of the gathered buffer."""
 from __future__ import annotations
 
 import logging
@@ -21,7 +21,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from .engine import HipIndex, topk_merge
+from .engine import HipIndex, topk_merge_keys
 from .utils import list_shards, read_shard
 
 logger = logging.getLogger(__name__)
@@ -94,50 +94,67 @@ def distributed_parallel_retrieve(args, topk: int, global_topk: bool = False) ->
     return result
 
 
-def pack_topk(scores: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """[nq, k] (fp32 score, global id < 2^31) -> ONE int64 per entry: score bits << 32 | id.  An empty
-    slot (id -1) keeps id bits 0xFFFFFFFF.  8 bytes per entry: 80 KB per rank at nq = 1000, k = 10."""
-    bits = scores.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    return (bits << 32) | (ids.to(torch.int64) & 0xFFFFFFFF)
-
-
-def unpack_topk(packed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    sc = (packed >> 32).to(torch.int32).view(torch.float32)          # arithmetic shift, then truncation: exact bits
-    ids = (packed & 0xFFFFFFFF)
-    ids = torch.where(ids == 0xFFFFFFFF, torch.full_like(ids, -1), ids)
-    return sc, ids
-
-
 def sharded_search(index, queries: torch.Tensor, k: int, id_offset: int = 0, group=None,
-                   local_search: Optional[Callable] = None, merge: Optional[Callable] = None
+                   local_search_keys: Optional[Callable] = None, merge_keys: Optional[Callable] = None
                    ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Every rank holds `index` = its corpus shard (row j has global id id_offset + j) and the
     same `queries` [nq, dim].  Returns the global (scores, ids) [nq, k] on every rank.
 
-    One exchange step: ONE all_gather_into_tensor of the packed [nq, k] (score, id) words (RCCL
-    over xGMI on GPUs), then the on-device merge.  `local_search(queries, k)` / `merge(all_sc,
-    all_ids)` default to the HipIndex search and vr_topk_merge; the CPU (gloo) test injects the
-    oracle's search and `merge_topk_host` so that THIS function is what runs under world_size 2."""
-    sc, ids = (local_search or index.search)(queries, k)
-    if not isinstance(sc, torch.Tensor):
-        sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
-    ids = torch.where(ids >= 0, ids + id_offset, ids)
+    The data path is three library calls and one collective, no tensor arithmetic in between:
+      1. `index.search_keys(queries, k, id_offset)` — the local fused search, whose merge kernel writes
+         each result as ONE 64-bit word, orderable(score) << 32 | ~global_id (vr_index_search_keys);
+      2. ONE `all_gather_into_tensor` of those [nq, k] words (80 KB per rank at nq = 1000, k = 10;
+         RCCL over xGMI when the group's backend is nccl) — the only exchange step of the path;
+      3. `vr_topk_merge_keys` over the gathered buffer as it is.
+    `local_search_keys(queries, k, id_offset)` / `merge_keys(keys[world, nq, k])` default to those calls;
+    the CPU (gloo) test injects the host statements below so that THIS function runs under world_size 2."""
+    n_local = len(index) if index is not None else 0
+    if id_offset < 0 or id_offset + n_local >= 2 ** 32 - 1:
+        raise ValueError("global row ids must stay below 2^32 - 1 for the packed exchange")
+    keys = (local_search_keys or index.search_keys)(queries, k, id_offset)
+    if not isinstance(keys, torch.Tensor):
+        keys = torch.from_numpy(np.ascontiguousarray(keys))
+    merge = merge_keys or topk_merge_keys
     dist = torch.distributed
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return sc, ids
-    if int(ids.max()) >= 2 ** 31 - 1:
-        raise ValueError("global row ids must stay below 2^31 - 1 for the packed exchange")
+        return merge(keys.view((1,) + tuple(keys.shape)))
     world = dist.get_world_size(group)
-    mine = pack_topk(sc, ids)
-    nq = mine.shape[0]
-    dev = mine.device
+    nq, dev = keys.shape[0], keys.device
+    mine = keys.contiguous()
     if mine.is_cuda and dist.get_backend(group) == "gloo":
         mine = mine.cpu()        # gloo rendezvous (no RCCL: e.g. two ranks sharing one GPU in the tests): exchange on the host
-    gathered = torch.empty((world * nq,) + tuple(mine.shape[1:]), dtype=torch.int64, device=mine.device)
+    gathered = torch.empty((world * nq, k), dtype=torch.int64, device=mine.device)
     dist.all_gather_into_tensor(gathered, mine, group=group)             # the one collective of the path
-    gathered = gathered.to(dev)
-    all_sc, all_ids = unpack_topk(gathered.view((world, nq) + tuple(mine.shape[1:])))
-    return (merge or topk_merge)(all_sc.contiguous(), all_ids.contiguous())
+    return merge(gathered.to(dev).view(world, nq, k))
+
+
+# ---- host statements of the exchange format (tests; the product path above never calls them) ----
+def pack_keys_host(scores: np.ndarray, ids: np.ndarray, id_offset: int = 0) -> np.ndarray:
+    """(fp32 score, local row id or -1) -> the packed key of include/visrag_hip.h as int64 bit patterns."""
+    u = np.ascontiguousarray(scores, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    ordr = np.where(u >> np.uint64(31), u ^ np.uint64(0xFFFFFFFF), u ^ np.uint64(0x80000000))
+    gid = (np.asarray(ids, dtype=np.int64) + id_offset).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    keys = (ordr << np.uint64(32)) | (gid ^ np.uint64(0xFFFFFFFF))
+    return np.where(np.asarray(ids) >= 0, keys, np.uint64(0)).view(np.int64)
+
+
+def unpack_keys_host(keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    k = np.ascontiguousarray(keys).view(np.uint64)
+    o = (k >> np.uint64(32)).astype(np.uint32)
+    u = np.where(o >> np.uint32(31), o ^ np.uint32(0x80000000), o ^ np.uint32(0xFFFFFFFF)).astype(np.uint32)
+    sc = u.view(np.float32)
+    ids = ((k & np.uint64(0xFFFFFFFF)) ^ np.uint64(0xFFFFFFFF)).astype(np.int64)
+    none = k == 0
+    return np.where(none, -np.inf, sc).astype(np.float32), np.where(none, -1, ids)
+
+
+def merge_keys_host(keys: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """[world, nq, kk] packed keys -> (scores, global ids) [nq, k]: larger key first — the merge rule
+    (score desc, id asc) is the integer order of the keys."""
+    P, nq, kk = keys.shape
+    u = np.transpose(np.ascontiguousarray(keys).view(np.uint64), (1, 0, 2)).reshape(nq, P * kk)
+    order = np.argsort(~u, axis=1, kind="stable")[:, :k]
+    return unpack_keys_host(np.take_along_axis(u, order, 1).view(np.int64))
 
 
 def merge_topk_host(all_sc: np.ndarray, all_ids: np.ndarray, k: int):
