@@ -66,6 +66,9 @@ typedef struct vr_config {
     int32_t max_patches;       /* workspace: patches per image slice (1024 for 448x448; <=1064 sliced) */
     int32_t max_tokens;        /* workspace: packed decoder tokens per vr_encode call */
     int32_t max_seqs;          /* workspace: sequences per vr_encode call */
+    int32_t text_split_precision; /* 1: token-only batches (queries, text passages) run the decoder on hi + lo bf16
+                                   * splits of activations and fp32 source weights with fp32 glue (fp32-class accuracy:
+                                   * the 1e-3 score bar for ~20-token queries); 0: the bf16 path for everything */
 } vr_config_t;
 
 /* ---- library ------------------------------------------------------------------------ */
@@ -115,6 +118,17 @@ int vr_encode(vr_model_t m,
               const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
               const int32_t* vision_rows,
               float* out_reps, int32_t out_on_device, void* stream);
+
+/* Pooling of the last hidden states (DRModel.encode, dense_retrieval_model.py:172-220), applied after the
+ * final RMSNorm and followed by the L2 normalisation (:222-223).  VisRAG-Ret's published setting is wmean
+ * (the default).  The reference's drop_wmean / drop_mean / lasttoken_simcse apply dropout in training mode
+ * even at inference (a fresh nn.Dropout1d, :187,196; F.dropout(training=True), :215): stochastic there,
+ * not offered here. */
+#define VR_POOL_WMEAN 0      /* sum_t (t+1) h_t / sum_t (t+1)        :180-184 */
+#define VR_POOL_MEAN 1       /* mean over the item's tokens           :204-207 */
+#define VR_POOL_LASTTOKEN 2  /* last_token_pool, right padding        :26-34,172-177 */
+#define VR_POOL_CLS 3        /* hidden[:, 0]                          :217-218 */
+int vr_model_set_pooling(vr_model_t m, int32_t mode);
 
 /* Debug taps for parity tests: copy an internal activation of the LAST vr_encode call to
  * host float32.  name in {"vit_embed","vit_block0","vit_out","resampler_out",

@@ -264,9 +264,28 @@ def wmean_pool_normalize(hidden: torch.Tensor, attn_mask_2d: torch.Tensor) -> to
     return reps / reps.norm(dim=1, keepdim=True).clamp_min(1e-12)
 
 
+def pool_normalize(hidden: torch.Tensor, attn_mask_2d: torch.Tensor, pooling: str = "wmean") -> torch.Tensor:
+    """The deterministic poolings of DRModel.encode (dense_retrieval_model.py:172-220) + F.normalize (:222-223):
+    wmean (:180-184), mean (:204-207), lasttoken = last_token_pool with right padding (:26-34,172-177),
+    cls = hidden[:, 0] (:217-218).  (drop_wmean / drop_mean / lasttoken_simcse apply dropout in training mode
+    even at inference — stochastic in the reference itself — and are not restated.)"""
+    m = attn_mask_2d.to(torch.int64)
+    if pooling == "wmean":
+        return wmean_pool_normalize(hidden, attn_mask_2d)
+    if pooling == "mean":
+        reps = torch.sum(hidden * m.unsqueeze(-1).float(), dim=1) / m.sum(dim=1, keepdim=True).float()
+    elif pooling == "lasttoken":
+        reps = hidden[torch.arange(hidden.shape[0]), m.sum(dim=1) - 1]
+    elif pooling == "cls":
+        reps = hidden[:, 0, :]
+    else:
+        raise ValueError("Unknown pooling type: {}".format(pooling))
+    return reps / reps.norm(dim=1, keepdim=True).clamp_min(1e-12)
+
+
 # ----------------------------------------------------------------------- whole model ---
 def encode(W, cfg, input_ids: Sequence[Sequence[int]], image_bounds: Sequence[Sequence[Tuple[int, int]]],
-           pixel_values: Sequence[Sequence[np.ndarray]], taps: Optional[dict] = None) -> torch.Tensor:
+           pixel_values: Sequence[Sequence[np.ndarray]], taps: Optional[dict] = None, pooling: str = "wmean") -> torch.Tensor:
     """VisRAG_Ret.forward + pooling: modeling_visrag_ret.py:86-126,
     get_vllm_embedding modeling_minicpmv.py:124-171 (embedding * scale_emb, then scatter of
     the un-scaled vision rows into [start, end) of each image bound),
@@ -305,7 +324,7 @@ def encode(W, cfg, input_ids: Sequence[Sequence[int]], image_bounds: Sequence[Se
         hidden = decoder_forward(W, cfg, emb, mask, taps)
         if taps is not None:
             taps["last_hidden"] = hidden.clone()
-        return wmean_pool_normalize(hidden, mask)
+        return pool_normalize(hidden, mask, pooling)
 
 
 # ------------------------------------------------------------------------- retrieval ---

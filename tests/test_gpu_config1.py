@@ -66,14 +66,14 @@ def test_config1_encode_retrieve_top3(full_model, golden_dir, tmp_path, batch):
     # ---- embeddings and the whole score matrix vs the reference
     assert ((P * g["p_reps"]).sum(1)).min() > 1 - TOL
     assert ((Q * g["q_reps"]).sum(1)).min() > 1 - TOL
-    # every query x page score (1024 pairs).  Each side against the reference's other side meets the 1e-3 bar
-    # (measured: pages 3.9e-4, queries 9.7e-4 max — a ~20-token query averages less bf16 noise away than a
-    # 68-token page); the joint matrix adds the two errors: max 1.06e-3, rms 3.6e-4 measured, held to 1.25e-3.
-    # The scores the path RETURNS (top-k, below) are held to 1e-3.
+    # every query x page score (1024 pairs) within north_star's 1e-3.  The queries run the split-precision decoder pass
+    # (csrc/hp_text.hip: fp32-class, their side of the error is ~1e-5 — it was 9.7e-4 on the bf16 pass, which left the
+    # joint matrix at 1.06e-3); what remains is the pages' bf16 error (3.9e-4 max measured: a 68-token page averages it).
     S = Q @ P.T
     assert np.abs(g["q_reps"] @ P.T - g["scores"]).max() < TOL
-    assert np.abs(Q @ g["p_reps"].T - g["scores"]).max() < TOL
-    assert np.abs(S - g["scores"]).max() < 1.25 * TOL, np.abs(S - g["scores"]).max()
+    assert np.abs(Q @ g["p_reps"].T - g["scores"]).max() < 0.1 * TOL, np.abs(Q @ g["p_reps"].T - g["scores"]).max()
+    assert ((Q * g["q_reps"]).sum(1)).min() > 1 - 1e-6
+    assert np.abs(S - g["scores"]).max() < TOL, np.abs(S - g["scores"]).max()
     assert np.sqrt(((S - g["scores"]) ** 2).mean()) < 0.5 * TOL
 
     # ---- retrieval through the drop-in (reference semantics: union of per-shard top-k)

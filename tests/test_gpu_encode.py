@@ -110,7 +110,9 @@ def test_errors_are_loud(tiny_model):
     cfg, enc, model = tiny_model
     tok = StandInTokenizer(cfg.vocab_size)
     with pytest.raises(ValueError):
-        DRModelForInference(cfg, enc, pooling="mean")
+        DRModelForInference(cfg, enc, pooling="drop_wmean")          # stochastic in the reference itself
+    with pytest.raises(ValueError):
+        DRModelForInference(cfg, enc, pooling="no_such_pooling")
     items = prepare_batch(["x"], [None], tok, cfg, 16)
     items[0].input_ids[0] = cfg.vocab_size + 5
     with pytest.raises(VisragHipError):

@@ -24,7 +24,7 @@ class VRConfig(C.Structure):
         ("intermediate_size", C.c_int32), ("vocab_size", C.c_int32), ("rms_norm_eps", C.c_float),
         ("rope_theta", C.c_float), ("scale_emb", C.c_float), ("residual_scale", C.c_float),
         ("max_images", C.c_int32), ("max_patches", C.c_int32), ("max_tokens", C.c_int32),
-        ("max_seqs", C.c_int32),
+        ("max_seqs", C.c_int32), ("text_split_precision", C.c_int32),
     ]
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
                             C.POINTER(_i32), _i32, C.POINTER(_i32), _vp, _i32, _vp]),
     "vr_model_tap": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64]),
     "vr_model_set_taps": (C.c_int, [_vp, _i32]),
+    "vr_model_set_pooling": (C.c_int, [_vp, _i32]),
     "vr_model_set_profile": (C.c_int, [_vp, _i32]),
     "vr_model_get_profile": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "vr_index_create": (C.c_int, [C.c_int, _i32, _i64, C.POINTER(_vp)]),
@@ -151,4 +152,5 @@ def make_config(cfg, max_images: int, max_patches: int, max_tokens: int, max_seq
         num_layers=cfg.num_layers, num_heads=cfg.num_heads, intermediate_size=cfg.intermediate_size,
         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
         scale_emb=cfg.scale_emb, residual_scale=cfg.residual_scale, max_images=max_images,
-        max_patches=max_patches, max_tokens=max_tokens, max_seqs=max_seqs)
+        max_patches=max_patches, max_tokens=max_tokens, max_seqs=max_seqs,
+        text_split_precision=1 if getattr(cfg, "text_split_precision", True) else 0)

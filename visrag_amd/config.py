@@ -42,6 +42,11 @@ class VisRAGRetConfig:
     scale_resolution: int = 448
     max_slice_nums: int = 9
     slice_mode: bool = True
+    # engine option (not a checkpoint field): token-only batches run the decoder at fp32-class precision
+    # (hi + lo bf16 operand splits; csrc/hp_text.hip) — what keeps ~20-token queries inside the 1e-3 score bar
+    text_split_precision: bool = True
+    # pooling of DRModel.encode (dense_retrieval_model.py:150-223): wmean | mean | lasttoken | cls | drop_wmean | drop_mean
+    pooling: str = "wmean"
 
     @property
     def vit_head_dim(self) -> int:

@@ -27,7 +27,10 @@ extern "C" int vr_device_count(int* count) {
 
 
 struct VitBlock { Vec n1w, n1b, n2w, n2b; Linear qkv, proj, fc1, fc2; };
-struct DecLayer { Vec ln1, ln2; Linear qkv, o, gu, down; int parts_qkv = 0, parts_gu = 0; };
+struct DecLayer {
+    Vec ln1, ln2; Linear qkv, o, gu, down; int parts_qkv = 0, parts_gu = 0;
+    Linear qkv_lo, o_lo, gu_lo, down_lo;     // w - bf16(w) of fp32 source weights: the split-precision text path (hp_text.hip)
+};
 
 struct GridTables {
     int gh = 0, gw = 0;
@@ -41,6 +44,7 @@ struct vr_model_s {
     int device = 0;
     vr_config_t c{};
     bool finalized = false, taps_on = false;
+    int pool_mode = 0;                        // VR_POOL_*
     bool borrowed = false;                    // vr_model_clone: weights belong to another handle
     // dims
     int D = 0, Dp = 0, F = 0, Fp = 0, E = 0, I = 0, Ip = 0, Kpe = 0, Kpe_p = 0, Q = 0;
@@ -55,6 +59,7 @@ struct vr_model_s {
     bool has_query = false, has_inproj = false, has_inproj_b = false, has_pos = false;
     DevBuf r_q;                               // bf16 [64][E] projected queries
     DevBuf embed;  bool has_embed = false;    // bf16 [V][E]
+    DevBuf embed_lo; bool has_embed_lo = false;   // its low half (fp32 source, split-precision text path)
     std::vector<DecLayer> layers;
     Vec final_norm;
     DevBuf rope;                              // f32 [max_pos][64]
@@ -65,6 +70,7 @@ struct vr_model_s {
     DevBuf w_hvit, w_xn, w_qkv, w_att, w_mlp, w_kv32, w_xkv, w_KV, w_ratt, w_rout, w_rln;
     DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact, w_part;   // w_part: split-K partial products [3][T][E] f32
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
+    DevBuf w_hp_hi, w_hp_lo, w_hp_qkv, w_hp_att, w_hp_gu, w_seqof;   // split-precision text path (hp_text.hip)
     std::map<std::string, Tap> taps;
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
     // stream, elapsed times summed lazily in vr_model_get_profile
@@ -163,9 +169,9 @@ extern "C" int vr_model_destroy(vr_model_t m) {
         auto fl = [](Linear& l) { l.w.free(); l.b.free(); };
         fl(m->patch); fl(m->r_kvproj); fl(m->r_kv); fl(m->r_out); fl(m->r_proj);
         for (auto& b : m->blocks) { fl(b.qkv); fl(b.proj); fl(b.fc1); fl(b.fc2); b.n1w.v.free(); b.n1b.v.free(); b.n2w.v.free(); b.n2b.v.free(); }
-        for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); l.ln1.v.free(); l.ln2.v.free(); }
+        for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); fl(l.qkv_lo); fl(l.o_lo); fl(l.gu_lo); fl(l.down_lo); l.ln1.v.free(); l.ln2.v.free(); }
         for (Vec* v : {&m->vit_nw, &m->vit_nb, &m->r_lnq_w, &m->r_lnq_b, &m->r_lnkv_w, &m->r_lnkv_b, &m->r_lnpost_w, &m->r_lnpost_b, &m->final_norm}) v->v.free();
-        for (DevBuf* b : {&m->r_q, &m->embed, &m->rope}) b->free();
+        for (DevBuf* b : {&m->r_q, &m->embed, &m->embed_lo, &m->rope}) b->free();
     }
     for (auto& g : m->grids) { g.second.vit_pos.free(); g.second.pos_k.free(); }
     for (auto& pc : m->prof) for (hipEvent_t e : pc.ev) (void)hipEventDestroy(e);
@@ -174,7 +180,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
                       &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
-                      &m->w_pix, &m->w_out})
+                      &m->w_pix, &m->w_out, &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof})
         b->free();
     delete m;
     return VR_OK;
@@ -276,6 +282,12 @@ extern "C" int vr_model_load_weight(vr_model_t m, const char* name_c, const void
         if (!shape_is(shape, ndim, {c.vocab_size, E})) return bad_shape();
         VRCHK(m->embed.alloc(numel * 2));
         HIPCHK(launch_pack_weight(src, bf, c.vocab_size, E, E, 0, m->embed.p, E, c.vocab_size, 0, 0, 0));
+        m->has_embed_lo = false;
+        if (!bf && c.text_split_precision) {
+            VRCHK(m->embed_lo.alloc(numel * 2));
+            HIPCHK(launch_pack_weight(src, bf, c.vocab_size, E, E, 0, m->embed_lo.p, E, c.vocab_size, 0, 0, 0, 1));
+            m->has_embed_lo = true;
+        }
         HIPCHK(hipDeviceSynchronize());
         m->has_embed = true;
         return VR_OK;
@@ -289,23 +301,36 @@ extern "C" int vr_model_load_weight(vr_model_t m, const char* name_c, const void
         DecLayer& l = m->layers[n];
         if (sub == "input_layernorm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(l.ln1, src, bf, E, E); }
         if (sub == "post_attention_layernorm.weight") { if (numel != (size_t)E) return bad_shape(); return load_vec(l.ln2, src, bf, E, E); }
+        // fp32 source weights also leave their low halves (w - bf16(w)) for the split-precision text path; a bf16
+        // checkpoint has none (the two activation halves against the one weight are then the whole product)
+        const bool lo = !bf && c.text_split_precision;
         for (int part = 0; part < 3; ++part) {
             static const char* nm[3] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight"};
             if (sub == nm[part]) {
                 if (!shape_is(shape, ndim, {E, E})) return bad_shape();
                 l.parts_qkv |= 1 << part;
+                if (lo) VRCHK(load_linear_part(l.qkv_lo, 3 * E, E, src, bf, E, E, 0, E, 0, part * E, 1));
                 return load_linear_part(l.qkv, 3 * E, E, src, bf, E, E, 0, E, 0, part * E);
             }
         }
-        if (sub == "self_attn.o_proj.weight") { if (!shape_is(shape, ndim, {E, E})) return bad_shape(); return load_linear_part(l.o, E, E, src, bf, E, E, 0, E, 0, 0); }
+        if (sub == "self_attn.o_proj.weight") {
+            if (!shape_is(shape, ndim, {E, E})) return bad_shape();
+            if (lo) VRCHK(load_linear_part(l.o_lo, E, E, src, bf, E, E, 0, E, 0, 0, 1));
+            return load_linear_part(l.o, E, E, src, bf, E, E, 0, E, 0, 0);
+        }
         if (sub == "mlp.gate_proj.weight" || sub == "mlp.up_proj.weight") {
             if (!shape_is(shape, ndim, {I, E})) return bad_shape();
             const int up = sub == "mlp.up_proj.weight";
             l.parts_gu |= 1 << up;
             // 16-row interleave: [16 gate | 16 up | ...] (EPI_SWIGLU)
+            if (lo) VRCHK(load_linear_part(l.gu_lo, 2 * I, E, src, bf, I, E, 0, 16, 32, up * 16, 1));
             return load_linear_part(l.gu, 2 * I, E, src, bf, I, E, 0, 16, 32, up * 16);
         }
-        if (sub == "mlp.down_proj.weight") { if (!shape_is(shape, ndim, {E, I})) return bad_shape(); return load_linear_part(l.down, E, I, src, bf, E, I, 0, E, 0, 0); }
+        if (sub == "mlp.down_proj.weight") {
+            if (!shape_is(shape, ndim, {E, I})) return bad_shape();
+            if (lo) VRCHK(load_linear_part(l.down_lo, E, I, src, bf, E, I, 0, E, 0, 0, 1));
+            return load_linear_part(l.down, E, I, src, bf, E, I, 0, E, 0, 0);
+        }
         return fail(VR_ERR_INVALID, "unknown decoder key %s", name_c);
     }
     return fail(VR_ERR_INVALID, "unknown weight key %s", name_c);
@@ -430,6 +455,15 @@ static int alloc_workspace(vr_model_s* m) {
     VRCHK(m->w_rowmap.alloc((size_t)R * 4));
     VRCHK(m->w_imgptr.alloc((size_t)c.max_images * 8));
     VRCHK(m->w_out.alloc((size_t)c.max_seqs * E * 4));
+    if (c.text_split_precision) {
+        const int Kmax = std::max(E, m->Ip);
+        VRCHK(m->w_hp_hi.alloc((size_t)T * Kmax * 2));
+        VRCHK(m->w_hp_lo.alloc((size_t)T * Kmax * 2));
+        VRCHK(m->w_hp_qkv.alloc((size_t)T * 3 * E * 4));
+        VRCHK(m->w_hp_att.alloc((size_t)T * E * 4));
+        VRCHK(m->w_hp_gu.alloc((size_t)T * pad128(2 * m->I) * 4));
+        VRCHK(m->w_seqof.alloc((size_t)T * 4));
+    }
     return VR_OK;
 }
 
@@ -508,6 +542,26 @@ extern "C" int vr_model_finalize(vr_model_t m) {
         VRCHK(m->rope.alloc(tab.size() * 4));
         HIPCHK(hipMemcpy(m->rope.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     }
+    // ---- split-precision text path: a checkpoint whose fp32 weights are bf16-exact (or that came as bf16) has no
+    //      low halves — drop the all-zero buffers, the passes over them would add nothing but weight reads
+    if (c.text_split_precision) {
+        DevBuf flag;
+        VRCHK(flag.alloc(4));
+        for (auto& l : m->layers)
+            for (Linear* L : {&l.qkv_lo, &l.o_lo, &l.gu_lo, &l.down_lo})
+                if (L->has_w) HIPCHK(launch_any_nonzero16(L->w.p, L->w.bytes / 2, flag.as<int>(), 0));
+        int any = 0;
+        HIPCHK(hipMemcpy(&any, flag.p, 4, hipMemcpyDeviceToHost));
+        if (!any)
+            for (auto& l : m->layers)
+                for (Linear* L : {&l.qkv_lo, &l.o_lo, &l.gu_lo, &l.down_lo}) { L->w.free(); L->has_w = false; }
+        if (m->has_embed_lo) {
+            HIPCHK(hipMemset(flag.p, 0, 4));
+            HIPCHK(launch_any_nonzero16(m->embed_lo.p, m->embed_lo.bytes / 2, flag.as<int>(), 0));
+            HIPCHK(hipMemcpy(&any, flag.p, 4, hipMemcpyDeviceToHost));
+            if (!any) { m->embed_lo.free(); m->has_embed_lo = false; }
+        }
+    }
     if (!m->w_h.p) VRCHK(alloc_workspace(m));
     m->finalized = true;
     return VR_OK;
@@ -578,6 +632,13 @@ static int tap_store(vr_model_s* m, const char* name, const void* dev, int64_t r
                 t.data[(size_t)r * cols + cc] = f;
             }
         }
+    return VR_OK;
+}
+
+extern "C" int vr_model_set_pooling(vr_model_t m, int32_t mode) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    if (mode < VR_POOL_WMEAN || mode > VR_POOL_CLS) return fail(VR_ERR_INVALID, "pooling mode %d: 0 wmean, 1 mean, 2 lasttoken, 3 cls", mode);
+    m->pool_mode = mode;
     return VR_OK;
 }
 
@@ -695,6 +756,56 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     return VR_OK;
 }
 
+// ---- the decoder pass of a token-only batch at fp32-class precision (hp_text.hip) -----------------------------
+// out (+)= alpha * A W^T with A = hi + lo (bf16 halves in w_hp_hi / w_hp_lo, row pitch lda) and W = L (+ Llo):
+// A_hi W_hi, then A_lo W_hi and A_hi W_lo added in place by the residual epilogue of the same MFMA kernels.
+static int hp_gemm(vr_model_s* m, const Linear& L, const Linear& Llo, int lda, int T, float* out, int ldo, bool into_resid,
+                   float alpha, hipStream_t s) {
+    {
+        GemmArgs a = gemm_args(m->w_hp_hi.p, lda, L, T, out, ldo);
+        if (into_resid) { a.resid = out; a.alpha = alpha; }
+        HIPCHK(launch_gemm(a, into_resid ? EPI_RESID : EPI_F32, GEMM_VARIANT_AUTO, s));
+    }
+    {
+        GemmArgs a = gemm_args(m->w_hp_lo.p, lda, L, T, out, ldo);
+        a.resid = out; a.alpha = into_resid ? alpha : 1.0f;
+        HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
+    }
+    if (Llo.has_w) {
+        GemmArgs a = gemm_args(m->w_hp_hi.p, lda, Llo, T, out, ldo);
+        a.resid = out; a.alpha = into_resid ? alpha : 1.0f;
+        HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
+    }
+    return VR_OK;
+}
+
+static int run_decoder_hp(vr_model_s* m, int T, int B, int max_len, hipStream_t s) {
+    (void)max_len;
+    const vr_config_t& c = m->c;
+    const int E = m->E, I = m->I, Ip = m->Ip;
+    float* h = m->w_h.as<float>();
+    float* qkv = m->w_hp_qkv.as<float>();
+    float* att = m->w_hp_att.as<float>();
+    float* gu = m->w_hp_gu.as<float>();
+    const int ld_gu = pad128(2 * I);
+    HIPCHK(launch_seq_of(m->w_seq.as<int>(), B, m->w_seqof.as<int>(), s));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const DecLayer& L = m->layers[l];
+        HIPCHK(launch_rmsnorm_split(h, T, E, L.ln1.v.as<float>(), c.rms_norm_eps, m->w_hp_hi.p, m->w_hp_lo.p, s));
+        VRCHK(hp_gemm(m, L.qkv, L.qkv_lo, E, T, qkv, 3 * E, false, 1.0f, s));
+        HIPCHK(launch_rope_f32(qkv, T, 3 * E, 2 * E, m->w_pos.as<int>(), m->rope.as<float>(), s));
+        HIPCHK(launch_attn_f32(qkv, 3 * E, E, m->w_seqof.as<int>(), m->w_seq.as<int>(), T, c.num_heads, 1.0f / sqrtf(64.0f), att, s));
+        HIPCHK(launch_split_bf16(att, m->w_hp_hi.p, m->w_hp_lo.p, (size_t)T * E, s));
+        VRCHK(hp_gemm(m, L.o, L.o_lo, E, T, h, E, true, c.residual_scale, s));
+        HIPCHK(launch_rmsnorm_split(h, T, E, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_hp_hi.p, m->w_hp_lo.p, s));
+        VRCHK(hp_gemm(m, L.gu, L.gu_lo, E, T, gu, ld_gu, false, 1.0f, s));
+        HIPCHK(launch_swiglu_split(gu, T, ld_gu, I, Ip, m->w_hp_hi.p, m->w_hp_lo.p, s));
+        VRCHK(hp_gemm(m, L.down, L.down_lo, Ip, T, h, E, true, c.residual_scale, s));
+        if (l == 0) VRCHK(tap_store(m, "dec_layer0", h, T, E, E, false, s));
+    }
+    return VR_OK;
+}
+
 static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
                        int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
                        const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream);
@@ -748,7 +859,12 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         HIPCHK(hipMemcpyAsync(m->w_ids.p, a_ids, (size_t)T * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(m->w_seq.p, a_seq, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
     }
-    HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, c.scale_emb, m->w_h.as<float>(), s));
+    // token-only batches (queries, text passages) take the split-precision decoder pass (hp_text.hip)
+    const bool hp = n_slices == 0 && c.text_split_precision != 0;
+    if (hp && m->has_embed_lo)
+        HIPCHK(launch_embed_gather_hp(m->w_ids.as<int>(), T, m->embed.p, m->embed_lo.p, E, c.scale_emb, m->w_h.as<float>(), s));
+    else
+        HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, c.scale_emb, m->w_h.as<float>(), s));
     HIPCHK(launch_iota_pos(m->w_seq.as<int>(), B, m->w_pos.as<int>(), s));
 
     // ---- vision: group slices by shape, chunk to the workspace
@@ -807,6 +923,9 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
     for (int i = 0; i < B; ++i) max_len = std::max(max_len, seq_offsets[i + 1] - seq_offsets[i]);
     if (max_len > m->rope_len) return fail(VR_ERR_CAPACITY, "sequence of %d tokens exceeds the RoPE table", max_len);
     VRCHK(prof_begin(m, VR_PROF_DECODER, s));
+    if (hp) {
+        VRCHK(run_decoder_hp(m, T, B, max_len, s));
+    } else {
     // o / down projections (N = E): with few rows the 256^2 grid is far smaller than the chip
     // (T = 2176: 81 tiles on 256 CUs; the 128^2 grid of 306 tiles runs 1.2 waves at 550-700 TF).
     // Split K over `ks` workgroups per tile instead (243 workgroups); the fp32 partial products are
@@ -882,6 +1001,7 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, ks, pstride, E, c.residual_scale, nullptr, c.rms_norm_eps, nullptr, 0, s));
         pend = false;
     }
+    }
     {
         double fl = 0;
         for (int i = 0; i < B; ++i) { const double Li = seq_offsets[i + 1] - seq_offsets[i]; fl += 4.0 * Li * Li * E; }
@@ -892,7 +1012,7 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
     float* tap_hidden = nullptr;   // scratch f32 [T][E] for the post-norm hidden states
     if (m->taps_on && (size_t)T * E * 4 <= m->w_kv32.bytes) tap_hidden = m->w_kv32.as<float>();
     float* dst = out_on_device ? out_reps : m->w_out.as<float>();
-    HIPCHK(launch_pool(h, seq, B, E, m->final_norm.v.as<float>(), c.rms_norm_eps, dst, tap_hidden, s));
+    HIPCHK(launch_pool(h, seq, B, E, m->final_norm.v.as<float>(), c.rms_norm_eps, dst, tap_hidden, s, m->pool_mode));
     if (tap_hidden) VRCHK(tap_store(m, "last_hidden", tap_hidden, T, E, E, false, s));
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out_reps, dst, (size_t)B * E * 4, hipMemcpyDeviceToHost, s));
     if (!out_on_device || (n_slices > 0 && !slices_on_device)) HIPCHK(hipStreamSynchronize(s));   // host buffers consumed
@@ -911,7 +1031,8 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     m->borrowed = true;
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
-                      &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out}) {
+                      &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out,
+                      &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof}) {
         b->free();                                 // (a non-owning alias after the copy: just forget it)
     }
     m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)

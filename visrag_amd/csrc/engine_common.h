@@ -128,14 +128,14 @@ static inline int stage(const void* data, size_t bytes, int on_device, Staged& s
 
 // rows of a [n][k] weight go to rows (r/blk)*blk_stride + blk_off + r%blk of the padded dst
 static inline int load_linear_part(Linear& L, int n_total, int k, const void* dev_src, int is_bf16, int rows, int src_ld,
-                            int transpose, int blk, int blk_stride, int blk_off) {
+                            int transpose, int blk, int blk_stride, int blk_off, int lo_part = 0) {
     if (!L.w.p) {
         L.n = n_total; L.k = k; L.n_pad = pad128(n_total); L.k_pad = pad128(k);
         VRCHK(L.w.alloc((size_t)pad256(n_total) * L.k_pad * 2));   // rows readable by a 256-row tile
     } else if (L.n != n_total || L.k != k) {
         return fail(VR_ERR_INVALID, "inconsistent shapes for a packed weight");
     }
-    HIPCHK(launch_pack_weight(dev_src, is_bf16, rows, k, src_ld, transpose, L.w.p, L.k_pad, blk, blk_stride, blk_off, 0));
+    HIPCHK(launch_pack_weight(dev_src, is_bf16, rows, k, src_ld, transpose, L.w.p, L.k_pad, blk, blk_stride, blk_off, 0, lo_part));
     HIPCHK(hipDeviceSynchronize());
     L.has_w = true;
     return VR_OK;

@@ -126,13 +126,24 @@ hipError_t launch_embed_gather(const int* ids, int T, const void* table, int dim
                                float* out, hipStream_t s);
 // final RMSNorm + position-weighted mean pool + L2 normalise: one embedding per sequence.
 hipError_t launch_pool(const float* h, const int* seq_offsets, int B, int dim, const float* norm_w,
-                       float eps, float* out, float* tap_hidden, hipStream_t s);
+                       float eps, float* out, float* tap_hidden, hipStream_t s, int mode = 0);   // mode: VR_POOL_*
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s,
                                   int* zero_word = nullptr);   // + zero tail (+ one int cleared)
 // split x (f32) into hi + lo bf16 parts (x ~= hi + lo to ~16 bits of mantissa)
 hipError_t launch_split_bf16(const float* in, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t launch_iota_pos(const int* seq_offsets, int B, int* pos, hipStream_t s);
+hipError_t launch_any_nonzero16(const void* p, size_t n, int* flag, hipStream_t s);   // *flag |= any bf16 word != +-0
+
+// ---- split-precision text path (hp_text.hip): fp32 glue between hi + lo bf16 GEMMs ---------------
+hipError_t launch_rmsnorm_split(const float* x, int rows, int dim, const float* w, float eps, void* hi, void* lo, hipStream_t s);
+hipError_t launch_rope_f32(float* qkv, int T, int ld, int rope_cols, const int* pos, const float* table, hipStream_t s);
+hipError_t launch_attn_f32(const float* qkv, int ld, int E, const int* seq_of, const int* seq_offsets, int T, int heads,
+                           float scale, float* out, hipStream_t s);
+hipError_t launch_swiglu_split(const float* gu, int T, int ld_gu, int I, int ld_act, void* hi, void* lo, hipStream_t s);
+hipError_t launch_embed_gather_hp(const int* ids, int T, const void* table_hi, const void* table_lo, int dim, float scale,
+                                  float* out, hipStream_t s);
+hipError_t launch_seq_of(const int* seq_offsets, int B, int* seq_of, hipStream_t s);
 
 // ---- PIL-exact bicubic resize (resize.hip) ------------------------------------------------------
 } // namespace vr

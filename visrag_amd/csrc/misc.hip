@@ -36,10 +36,12 @@ hipError_t launch_embed_gather(const int* ids, int T, const void* table, int dim
 // w, w+4, ...; a lane keeps dim/64 running sums in registers.
 constexpr int POOL_MAXV = 10;
 
+// mode: 0 wmean (w_t = t + 1), 1 mean, 2 lasttoken (last_token_pool, right padding: dense_retrieval_model.py:26-34),
+// 3 cls (hidden[:, 0]: :217-218) — the deterministic poolings of DRModel.encode (:172-220)
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ h,
                                                    const int* __restrict__ seq_offsets, int dim,
                                                    const float* __restrict__ norm_w, float eps,
-                                                   float* __restrict__ out, float* __restrict__ tap) {
+                                                   float* __restrict__ out, float* __restrict__ tap, int mode) {
     __shared__ float red[4][64 * 4 * POOL_MAXV];
     __shared__ float red_s[4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ h,
         }
         ss = wave_sum(ss);
         const float rstd = rsqrtf(ss / dim + eps);
-        const float wt = (float)(t + 1);
+        const float wt = mode == 0 ? (float)(t + 1) : mode == 1 ? 1.0f : mode == 2 ? (t == L - 1 ? 1.0f : 0.0f) : (t == 0 ? 1.0f : 0.0f);
 #pragma unroll
         for (int i = 0; i < POOL_MAXV; ++i) {
             const f32x4 y = v[i] * rstd * ww[i];
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ h,
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(lane + i * 64) * 4 + r] = acc[i][r];
     __syncthreads();
-    const float denom = 0.5f * (float)L * (float)(L + 1);   // sum_{t=1..L} t
+    const float denom = mode == 0 ? 0.5f * (float)L * (float)(L + 1) : mode == 1 ? (float)L : 1.0f;   // sum of the weights
     float sq = 0.f;
     float vals[POOL_MAXV];
 #pragma unroll
@@ -101,11 +103,11 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ h,
 }
 
 hipError_t launch_pool(const float* h, const int* seq_offsets, int B, int dim, const float* norm_w,
-                       float eps, float* out, float* tap_hidden, hipStream_t s) {
+                       float eps, float* out, float* tap_hidden, hipStream_t s, int mode) {
     if (B <= 0) return hipSuccess;
-    if (dim % 4 || dim > 64 * 4 * POOL_MAXV) return hipErrorInvalidValue;
+    if (dim % 4 || dim > 64 * 4 * POOL_MAXV || mode < 0 || mode > 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pool_kernel, dim3(B), dim3(256), 0, s, h, seq_offsets, dim, norm_w, eps, out,
-                       tap_hidden);
+                       tap_hidden, mode);
     return hipGetLastError();
 }
 
@@ -187,6 +189,21 @@ __global__ void iota_pos_kernel(const int* __restrict__ seq_offsets, int* __rest
 hipError_t launch_iota_pos(const int* seq_offsets, int B, int* pos, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(iota_pos_kernel, dim3(B), dim3(256), 0, s, seq_offsets, pos);
+    return hipGetLastError();
+}
+
+// *flag |= 1 if any of the n 16-bit words is non-zero (load time: is the low half of a weight split empty?)
+__global__ void any_nonzero16_kernel(const uint16_t* __restrict__ p, size_t n, int* __restrict__ flag) {
+    int any = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        any |= (p[i] & 0x7FFFu) != 0;
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+hipError_t launch_any_nonzero16(const void* p, size_t n, int* flag, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(any_nonzero16_kernel, dim3(blocks), dim3(256), 0, s, (const uint16_t*)p, n, flag);
     return hipGetLastError();
 }
 

@@ -2,9 +2,10 @@
 #include <hip/hip_runtime.h>
 namespace vr {
 // dst[(r/blk)*blk_stride + blk_off + r%blk][c] = (transpose ? src[c][r] : src[r][c]) as bf16
+// lo_part: store bf16(v - bf16(v)) instead — the low half of a hi + lo split of an fp32 weight (hp_text.hip)
 hipError_t launch_pack_weight(const void* src, int src_is_bf16, int rows, int cols, int src_ld,
                               int transpose, void* dst, int dst_ld, int blk, int blk_stride, int blk_off,
-                              hipStream_t s);
+                              hipStream_t s, int lo_part = 0);
 // dst[(r/rblk)*rstride + r%rblk][(c/cblk)*cstride + c%cblk] = src[r][c] as bf16
 hipError_t launch_pack_weight_blocks(const void* src, int src_is_bf16, int rows, int cols, int src_ld, void* dst, int dst_ld,
                                      int rblk, int rstride, int cblk, int cstride, hipStream_t s);

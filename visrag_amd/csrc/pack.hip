@@ -9,12 +9,13 @@ namespace vr {
 template <typename SrcT>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const SrcT* __restrict__ src, int rows, int cols,
                                                           int src_ld, int transpose, bf16_t* __restrict__ dst,
-                                                          int dst_ld, int blk, int blk_stride, int blk_off) {
-    // dst[map(r)][c] = transpose ? src[c][r] : src[r][c]
+                                                          int dst_ld, int blk, int blk_stride, int blk_off, int lo_part) {
+    // dst[map(r)][c] = transpose ? src[c][r] : src[r][c]   (lo_part: what bf16 rounding left over, v - bf16(v))
     const size_t n = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / cols), c = (int)(i % cols);
-        const float v = transpose ? (float)src[(size_t)c * src_ld + r] : (float)src[(size_t)r * src_ld + c];
+        float v = transpose ? (float)src[(size_t)c * src_ld + r] : (float)src[(size_t)r * src_ld + c];
+        if (lo_part) v -= bf2f(f2bf(v));
         const int dr = (r / blk) * blk_stride + blk_off + (r % blk);
         dst[(size_t)dr * dst_ld + c] = f2bf(v);
     }
@@ -22,16 +23,16 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const SrcT* __restrict
 
 hipError_t launch_pack_weight(const void* src, int src_is_bf16, int rows, int cols, int src_ld,
                               int transpose, void* dst, int dst_ld, int blk, int blk_stride, int blk_off,
-                              hipStream_t s) {
+                              hipStream_t s, int lo_part) {
     const size_t n = (size_t)rows * cols;
     if (n == 0) return hipSuccess;
     const int blocks = (int)min((size_t)4096, (n + 255) / 256);
     if (src_is_bf16)
         hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, rows,
-                           cols, src_ld, transpose, (bf16_t*)dst, dst_ld, blk, blk_stride, blk_off);
+                           cols, src_ld, transpose, (bf16_t*)dst, dst_ld, blk, blk_stride, blk_off, lo_part);
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)src, rows,
-                           cols, src_ld, transpose, (bf16_t*)dst, dst_ld, blk, blk_stride, blk_off);
+                           cols, src_ld, transpose, (bf16_t*)dst, dst_ld, blk, blk_stride, blk_off, lo_part);
     return hipGetLastError();
 }
 

@@ -68,6 +68,14 @@ class HipEncoder:
         except Exception:
             pass
 
+    POOLINGS = {"wmean": 0, "mean": 1, "lasttoken": 2, "cls": 3}
+
+    def set_pooling(self, pooling: str) -> None:
+        """DRModel.encode's pooling (dense_retrieval_model.py:172-220); clones made afterwards inherit it."""
+        if pooling not in self.POOLINGS:
+            raise ValueError("Unknown pooling type: {}".format(pooling))
+        _lib.check(self.lib.vr_model_set_pooling(self._h, self.POOLINGS[pooling]), "vr_model_set_pooling")
+
     # ---- weights --------------------------------------------------------------------------
     def load_weight(self, name: str, t: torch.Tensor) -> None:
         if t.dtype == torch.bfloat16:

@@ -38,9 +38,15 @@ class DRModelForInference:
 
     def __init__(self, cfg: VisRAGRetConfig, encoder: HipEncoder, pooling: str = "wmean",
                  normalize: bool = True, gpu_preprocess: bool = True):
-        if pooling != "wmean":
-            raise ValueError("Unknown pooling type: {} (the HIP path fuses 'wmean')".format(pooling))
+        if pooling in ("drop_wmean", "drop_mean", "lasttoken_simcse"):
+            # the reference applies dropout in TRAINING mode inside these even at inference (a fresh nn.Dropout1d(0.3),
+            # dense_retrieval_model.py:187,196; F.dropout(training=True), :215): its own output is random
+            raise ValueError(f"pooling {pooling!r} is stochastic in the reference (training-mode dropout); use "
+                             "wmean / mean / lasttoken / cls")
+        if pooling not in HipEncoder.POOLINGS:
+            raise ValueError("Unknown pooling type: {}".format(pooling))      # dense_retrieval_model.py:220
         assert normalize == True, "Normalize must be true"   # dense_retrieval_model.py:222
+        encoder.set_pooling(pooling)
         self.cfg, self.encoder = cfg, encoder
         self.pooling, self.normalize = pooling, normalize
         self.micro_batch = encoder.max_seqs
@@ -65,7 +71,8 @@ class DRModelForInference:
         reference's `encoding_args.device`: this process's LOCAL_RANK under torchrun, else torch's
         current device — one process per GPU, never "all ranks on GPU 0"."""
         device = default_device() if device is None else _device_index(device)
-        pooling = getattr(model_args, "pooling", "wmean") if model_args is not None else "wmean"
+        pooling = (getattr(model_args, "pooling", None) if model_args is not None else None) or \
+                  (getattr(cfg, "pooling", None) if cfg is not None else None) or "wmean"
         normalize = getattr(model_args, "normalize", True) if model_args is not None else True
         path = getattr(model_args, "model_name_or_path", None) if model_args is not None else None
         if cfg is None:
@@ -145,7 +152,10 @@ class DRModelForInference:
         for it in prepared:
             n = len(it.input_ids)
             if n > enc.max_tokens:
-                raise ValueError(f"sequence of {n} tokens exceeds max_tokens={enc.max_tokens}")
+                # (items are already truncated to max_inp_length like the reference's _convert_to_tensors,
+                # modeling_minicpmv.py:179-180: this is the WORKSPACE being smaller than max_inp_length)
+                raise ValueError(f"sequence of {n} tokens exceeds the encoder workspace (max_tokens={enc.max_tokens}): build "
+                                 "with max_tokens >= max_inp_length")
             if cur and (tok + n > enc.max_tokens or len(cur) >= enc.max_seqs):
                 outs.append(enc.encode_items(cur)); cur, tok = [], 0
             cur.append(it); tok += n
