@@ -99,7 +99,9 @@ class QwenGenOracle:
     def embed(self, ids: torch.Tensor) -> torch.Tensor:
         return self.w["model.language_model.embed_tokens.weight"][ids.long()]
 
-    def forward(self, x: torch.Tensor, pos3: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pos3: torch.Tensor, last_only: bool = False) -> torch.Tensor:
+        """last_only: logits of the last new token only ([1][vocab]) — a 1405-token prompt against a 152k vocabulary
+        would otherwise spend most of its time and 0.9 GB on rows nobody reads."""
         c = self.cfg
         H, KV, hd = c.num_attention_heads, c.num_key_value_heads, c.head_dim
         T = x.shape[0]
@@ -127,7 +129,7 @@ class QwenGenOracle:
             xn = rmsnorm(h, w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
             act = torch.nn.functional.silu(xn @ w[p + "mlp.gate_proj.weight"].T) * (xn @ w[p + "mlp.up_proj.weight"].T)
             h = h + act @ w[p + "mlp.down_proj.weight"].T
-        hn = rmsnorm(h, self.w["model.language_model.norm.weight"], c.rms_norm_eps)
+        hn = rmsnorm(h[-1:] if last_only else h, self.w["model.language_model.norm.weight"], c.rms_norm_eps)
         return hn @ self.w["lm_head.weight"].T
 
 

@@ -237,7 +237,12 @@ def test_build_flags_compiler_use_of_accumulation_registers():
     """
     assert agpr_violations(ok) == []
     spill = ok + "\n\tv_accvgpr_write_b32 a17, v1 ; the compiler parking a VGPR\n"
-    assert agpr_violations(spill) == ["v_accvgpr_write_b32 a17, v1 ; the compiler parking a VGPR"]
+    assert agpr_violations(spill) == ["v_accvgpr_write_b32 a17, v1"]
+    # gfx950 can address accumulation registers directly: any a-register OPERAND outside the asm blocks counts, a
+    # comment that mentions one does not, and neither does a spilled VGPR go unnoticed
+    direct = ok + "\n\tds_read_b128 a[0:3], v5\n\tscratch_store_dword off, a5, s0\n\tv_mov_b32 v1, v2 ; not a5\n"
+    assert agpr_violations(direct) == ["ds_read_b128 a[0:3], v5", "scratch_store_dword off, a5, s0"]
+    assert len(agpr_violations(ok + "\n\t.vgpr_spill_count: 2\n")) == 1 and agpr_violations(ok + "\n\t.vgpr_spill_count: 0\n") == []
     assert AGPR_CHECKED <= set(SOURCES) and {"gemm256w.hip", "search256w.hip"} <= AGPR_CHECKED
 
 

@@ -10,6 +10,7 @@ and the tests always use the untagged library.
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -51,8 +52,14 @@ def _newest_header() -> float:
     return t
 
 
+_AGPR_OPERAND = re.compile(r"(?<![\w.$])a(\d+|\[\d+:\d+\])(?![\w])")
+
+
 def agpr_violations(asm_text: str) -> List[str]:
-    """Instructions of a `hipcc -S` listing that touch accumulation registers outside `;;#ASMSTART ... ;;#ASMEND`."""
+    """Instructions of a `hipcc -S` listing that touch accumulation registers outside `;;#ASMSTART ... ;;#ASMEND`:
+    `v_accvgpr_*` moves AND any other instruction with an a-register operand (on gfx950 the compiler may address them
+    directly: `ds_read_b128 a[0:3], ...`, `global_load_dwordx4 a[..]`, `scratch_store_dword ..., a5`, an MFMA with
+    `a[..]` as source or destination).  Also reports VGPR spills of the file's kernels (`.vgpr_spill_count`)."""
     bad, in_asm = [], False
     for ln in asm_text.splitlines():
         t = ln.strip()
@@ -60,8 +67,14 @@ def agpr_violations(asm_text: str) -> List[str]:
             in_asm = True
         elif t.startswith(";;#ASMEND"):
             in_asm = False
-        elif not in_asm and t.startswith("v_accvgpr"):
-            bad.append(t)
+        elif not in_asm and t and not t.startswith((".", ";", "//")) and not t.endswith(":"):
+            code = t.split(";", 1)[0]
+            parts = code.split(None, 1)
+            if parts[0].startswith("v_accvgpr") or (len(parts) > 1 and _AGPR_OPERAND.search(parts[1])):
+                bad.append(code.strip())
+        elif not in_asm and t.startswith(".vgpr_spill_count:"):
+            if int(t.split(":", 1)[1]) != 0:
+                bad.append(t + "   (a spilled VGPR next to hand-allocated accumulators)")
     return bad
 
 

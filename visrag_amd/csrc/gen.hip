@@ -56,6 +56,9 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
     if (c.num_heads <= 0 || c.hidden_size != c.num_heads * 128) return fail(VR_ERR_INVALID, "head_dim must be 128 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
     if (c.num_kv_heads <= 0 || c.num_heads % c.num_kv_heads) return fail(VR_ERR_INVALID, "num_heads must be a multiple of num_kv_heads");
     if (c.hidden_size % 256 || c.intermediate_size % 64 || c.vocab_size % 128) return fail(VR_ERR_INVALID, "hidden %% 256, intermediate %% 64, vocab %% 128 must be 0");
+    // the row-norm kernels hold a row in 14 float4 registers per lane (norm.hip: NORM_MAXV): 3584 columns — the 3B and 7B
+    // models; the 32B / 72B widths (5120 / 8192) would fail inside the first prefill instead
+    if (c.hidden_size > 3584) return fail(VR_ERR_INVALID, "hidden_size %d is beyond this build's row kernels (<= 3584: Qwen2.5-VL-3B / 7B)", c.hidden_size);
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return fail(VR_ERR_INVALID, "mrope sections must add up to 64 channel pairs");
     if (c.num_layers <= 0 || c.max_len <= 0 || c.max_prefill <= 0 || c.max_prefill > c.max_len) return fail(VR_ERR_INVALID, "bad layer / length settings");
     VRCHK(set_dev(device_id));

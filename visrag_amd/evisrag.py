@@ -462,7 +462,8 @@ class LLM:
     `limit_mm_per_prompt["image"]` images per prompt; `generate` takes one prompt at a time like predict.py:128-149."""
 
     def __init__(self, model, tensor_parallel_size: int = 1, dtype: str = "bfloat16",
-                 limit_mm_per_prompt: Optional[Dict[str, int]] = None, max_model_len: int = 8192, max_prefill: int = 4096,
+                 limit_mm_per_prompt: Optional[Dict[str, int]] = None, max_model_len: Optional[int] = None,
+                 max_prefill: Optional[int] = None,
                  device: int = 0, weights=None, detokenize: Optional[Callable[[List[int]], str]] = None,
                  vision: Optional[VisionConfig] = None, max_vision_rows: Optional[int] = None):
         if tensor_parallel_size != 1:
@@ -470,6 +471,15 @@ class LLM:
         if dtype not in ("bfloat16", "bf16"):
             raise ValueError("the generator computes in bf16 (predict.py:115)")
         self.tokenizer = None
+        # Lengths.  vLLM sizes itself from the checkpoint (128k context); here the KV cache and the prefill workspace are
+        # allocated up front: a checkpoint directory gets room for predict.py's workload — five pages at the
+        # processor's largest size are 5 x 3 333 image tokens — a bare GenConfig (tests, benchmarks) stays small.
+        # A prompt beyond either limit is refused by generate() BEFORE the tower runs.
+        from_dir = isinstance(model, str)
+        if max_model_len is None:
+            max_model_len = 32768 if from_dir else 8192
+        if max_prefill is None:
+            max_prefill = min(max_model_len, 24576 if from_dir else 4096)
         if isinstance(model, str):                     # a checkpoint directory, like predict.py:112's model_path
             model_dir = model
             model, ck_vision, tied = read_checkpoint_configs(model_dir)
@@ -662,6 +672,17 @@ class LLM:
         self.run_end()
         return toks
 
+    def _check_lengths(self, n_tokens: int, n_vision_rows: int) -> None:
+        """Refuse a prompt the allocations cannot hold, up front and in the caller's terms (the C ABI would answer
+        VR_ERR_CAPACITY after the tower has already run)."""
+        if n_tokens > self.max_prefill or n_tokens >= self.max_model_len:
+            raise ValueError(f"prompt of {n_tokens} tokens ({n_vision_rows // 4 if n_vision_rows else 0} of them image tokens) exceeds "
+                             f"max_prefill={self.max_prefill} / max_model_len={self.max_model_len}: construct "
+                             "LLM(..., max_model_len=..., max_prefill=...) for it")
+        if n_vision_rows and n_vision_rows > getattr(self, "max_vision_rows", 0):
+            raise ValueError(f"{n_vision_rows} patch rows exceed the tower's workspace (max_vision_rows={self.max_vision_rows}): "
+                             "construct LLM(..., max_vision_rows=...) or lower the processor's max_pixels")
+
     # ---- predict.py:147 ------------------------------------------------------------------------------------
     def generate(self, prompts, sampling_params: Optional[SamplingParams] = None, pipelined: bool = True) -> List[RequestOutput]:
         sp = sampling_params or SamplingParams()
@@ -675,13 +696,23 @@ class LLM:
             else:
                 raise ValueError("a text prompt needs the checkpoint's tokenizer: LLM(model=<checkpoint directory>), or pass prompt_token_ids")
             mm = pr.get("multi_modal_data") or {}
-            if mm.get("image") is not None or mm.get("pixel_values") is not None:
+            images = mm.get("image")
+            if images is not None and len(images) == 0:
+                images = None                         # a query with no retrieved page: a text-only prompt, like vLLM
+            if images is not None or mm.get("pixel_values") is not None:
                 if self.vision is None:
                     raise RuntimeError("images need a vision tower: LLM(..., vision=VisionConfig())")
                 px, grid = (mm["pixel_values"], mm["image_grid_thw"]) if mm.get("pixel_values") is not None \
-                    else process_images(mm["image"], self.vision)
+                    else process_images(images, self.vision)
+                m2 = self.vision.spatial_merge_size ** 2
+                g = np.asarray(grid).reshape(-1, 3)
+                n_tok = int((g[:, 0] * g[:, 1] * g[:, 2]).sum()) // m2
+                n_ph = sum(1 for t in ids if t == self.cfg.image_token_id)
+                total = len(ids) - n_ph + n_tok if n_ph == len(g) else len(ids)
+                self._check_lengths(total, n_tok * m2)
                 pos3, ids = self.prefill_images(ids, px, grid)
             else:
+                self._check_lengths(len(ids), 0)
                 pos3 = self.prefill(ids, mm.get("image_embeds", ()), mm.get("image_grids", ()), pr.get("positions"))
             nxt = int(pos3.max()) + 1
             limit = min(sp.max_tokens, self.max_model_len - len(ids))
