@@ -116,13 +116,18 @@ def main():
         step(i)
     barrier()
     index.reset()
-    enc.set_profile(True)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(args.steps):                       # the timed region of `value`: no events, no profiling inside
         step(i)
     barrier()
     dt = time.perf_counter() - t0
+    # per-kernel-class HIP events (roofline, phases) in a SECOND pass of the same steps: outside `value`
+    enc.set_profile(True)
+    for i in range(args.steps):
+        it, px = batches[i % len(batches)]
+        enc.encode_items(it, device_slices=px, out=out)
+    barrier()
     prof = enc.get_profile()
     enc.set_profile(False)
     def max_over_ranks(x: float) -> float:
@@ -190,6 +195,21 @@ def main():
     barrier()
     ds = max_over_ranks(time.perf_counter() - ts0)
     search_qps = args.queries * args.search_steps / ds
+    # the exchange step alone: ONE all-gather of the packed [nq, k] keys (8 B each) per search
+    gather_us = None
+    if world > 1:
+        mine = index.search_keys(Q, args.topk, id_offset=rank * rows_local)
+        if shared:
+            mine = mine.cpu()
+        buf = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=torch.int64, device=mine.device)
+        for _ in range(3):
+            dist.all_gather_into_tensor(buf, mine)
+        barrier()
+        tg0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_gather_into_tensor(buf, mine)
+        barrier()
+        gather_us = max_over_ranks(time.perf_counter() - tg0) / 20 * 1e6
     # event-timed local sweep (kernel time only, for the search roofline)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -199,6 +219,16 @@ def main():
     torch.cuda.synchronize()
     sweep_ms = e0.elapsed_time(e1) / args.search_steps
     search_flops = 2.0 * args.queries * len(index) * cfg.hidden_size
+    # per-stage split of the local search (HIP events inside vr_index_search; a separate pass: every profiled call ends
+    # with an event synchronisation) and what the top-k certification did with the queries
+    index.search_stats(reset=True)
+    index.set_search_profile(True)
+    for _ in range(args.search_steps):
+        index.search(Q, args.topk)
+    search_stages = index.get_search_profile()
+    index.set_search_profile(False)
+    cert = index.search_stats()
+    n_cert = max(1, sum(cert.values()))
     # the HBM-bound regime: ONE query against the local shard, bytes = bf16 index size
     for _ in range(3):
         index.search(Q[:1], args.topk)
@@ -261,10 +291,21 @@ def main():
         "queries_per_sec": round(search_qps, 1),
         "search": {"index_rows": args.index_rows, "rows_per_gpu": len(index), "queries": args.queries,
                    "k": args.topk, "ms_per_search": round(ds / args.search_steps * 1e3, 3),
+                   "exchange": None if world == 1 else {
+                       "collective": "all_gather_into_tensor of the packed [nq, k] 64-bit keys, one per search",
+                       "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "bytes_per_rank": args.queries * args.topk * 8, "all_gather_us": round(gather_us, 1)},
                    "local_sweep_ms": round(sweep_ms, 3),
                    "local_sweep_tflops": round(search_flops / (sweep_ms * 1e-3) / 1e12, 1),
                    "local_sweep_frac_of_mfma_peak": round(search_flops / (sweep_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                    "index_GBps": round(len(index) * cfg.hidden_size * 2 / (sweep_ms * 1e-3) / 1e9, 1),
+                   "stages_ms": {k: round(v, 4) for k, v in search_stages.items() if k != "calls"},
+                   "sweep_kernel_tflops": round(search_flops / max(search_stages["sweep"], 1e-9) / 1e9, 1),
+                   "certification": {"certified_at_once": round(cert["certified"] / n_cert, 4),
+                                     "certified_after_extended_rescoring": round(cert["certified_extended"] / n_cert, 4),
+                                     "exact_fp32_pass": round(cert["exact_pass"] / n_cert, 4),
+                                     "what": "fraction of queries; the ids returned are the fp32 ranking's (rigorous bf16 "
+                                             "error bound, visrag_hip.h: vr_index_search)"},
                    "query_encode_per_sec": round(args.queries / q_encode_s, 1),
                    "single_query": {"ms": round(one_ms, 4), "bound": "hbm",
                                     "index_GBps": round(len(index) * cfg.hidden_size * 2 / (one_ms * 1e-3) / 1e9, 1),
@@ -342,9 +383,14 @@ def main():
 
     # ---- CPU baseline: the oracle (fp32 restatement of the reference) on the host cores, rank 0, N=1.
     #      kind "port": /root/reference does not exist on the GPU box, so the timed code is oracle/ (pinned to
-    #      the reference by tests/test_oracle_golden.py).  The reference itself, timed in the build container by
-    #      the survey probe (8 cores): 0.52 pages/s, 1.8 queries/s (encode), 285 queries/s (retrieve 1k x 100k).
+    #      the reference by tests/test_oracle_golden.py).
     if world == 1 and not args.no_cpu_baseline:
+        # the reference ITSELF cannot run on the GPU box (no /root/reference there): its timing in the build container is
+        # re-measured by the committed tools/ref_cpu_baseline.py and read from the file that tool writes
+        try:
+            ref_in_container = json.load(open(os.path.join(ROOT, "profiles", "ref_cpu_baseline.json")))
+        except Exception:
+            ref_in_container = None
         try:
             from oracle import visrag_ret_oracle as O
             # 16 threads is the fastest setting for this fp32 forward on the many-core host
@@ -369,6 +415,11 @@ def main():
             qref = O.encode(W, cfg, [i.input_ids for i in qitems[:nq_cpu]], [[]] * nq_cpu, [[]] * nq_cpu)
             cpu_q_s = time.perf_counter() - tc
             qcos = float((Q[:nq_cpu].cpu() * qref).sum(1).min())
+            # north_star's bar is on SCORES: query x page scores of the GPU embeddings against the CPU restatement's
+            s_ref = qref @ ref.T
+            err_q = float((Q[:nq_cpu].cpu() @ ref.T - s_ref).abs().max())       # the queries' side alone
+            err_p = float((qref @ got.T - s_ref).abs().max())                   # the pages' side alone
+            err_joint = float((Q[:nq_cpu].cpu() @ got.T - s_ref).abs().max())
             # retrieval baseline: fp32 matmul + topk over the FULL index size (dense_retriever.py:28-30)
             gC = torch.Generator().manual_seed(7)
             Cc = torch.randn((args.index_rows, cfg.hidden_size), generator=gC); Cc = Cc / Cc.norm(dim=1, keepdim=True)
@@ -384,8 +435,9 @@ def main():
                 "query_encode_per_sec": round(nq_cpu / cpu_q_s, 2),
                 "queries_per_sec_search": round(args.queries / cpu_search_s, 1),
                 "parity_min_cosine_vs_gpu": round(cos, 6), "parity_min_cosine_queries": round(qcos, 6),
-                "reference_in_build_container": {"pages_per_sec": 0.52, "query_encode_per_sec": 1.8, "queries_per_sec_search": 285,
-                                                 "cores": 8, "source": "BASELINE.md section 3 (survey probe of the reference's own code)"}}
+                "parity_max_score_err": {"queries_side": round(err_q, 7), "pages_side": round(err_p, 7), "joint": round(err_joint, 7),
+                                         "pairs": f"{nq_cpu} queries x {n} pages", "bar": 1e-3},
+                "reference_in_build_container": ref_in_container}
         except Exception as e:   # the baseline is informational; never lose the GPU numbers
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(result), flush=True)

@@ -386,3 +386,53 @@ def test_search_keys_and_merge_keys(nd, nq, dim, k):
     assert torch.equal(mi, fi) and torch.equal(ms, fs)
     with pytest.raises(Exception):
         full.search_keys(q, k, id_offset=2 ** 32)
+
+
+NCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["VR_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device(f"cuda:{rank}"))        # RCCL
+from visrag_amd.engine import HipIndex
+from visrag_amd.retriever import sharded_search
+rng = np.random.default_rng(0)
+nd, nq, dim, k = 30011, 333, 512, 10
+C = rng.standard_normal((nd, dim)).astype(np.float32); C /= np.linalg.norm(C, axis=1, keepdims=True)
+Q = rng.standard_normal((nq, dim)).astype(np.float32); Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+C[20000] = C[5]
+per = (nd + world - 1) // world
+lo, hi = rank * per, min(nd, (rank + 1) * per)
+shard = HipIndex(dim, hi - lo, device=rank); shard.add(torch.from_numpy(C[lo:hi]).cuda())
+q = torch.from_numpy(Q).cuda()
+sc, ids = sharded_search(shard, q, k, id_offset=lo)       # search_keys -> ONE RCCL all-gather of device keys -> vr_topk_merge_keys
+assert dist.get_backend() == "nccl" and sc.is_cuda
+full = HipIndex(dim, nd, device=rank); full.add(torch.from_numpy(C).cuda())
+fs, fi = full.search(q, k)
+torch.cuda.synchronize()
+assert torch.equal(ids, fi) and torch.equal(sc, fs), rank
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_sharded_search_over_rccl(tmp_path):
+    """The multi-GPU retrieval path on its real transport: one process per GPU, backend "nccl" (= RCCL over xGMI),
+    the all-gather on DEVICE key buffers.  Skipped on the 1-GPU boxes of this pool; there the same function runs
+    over gloo (test_sharded_search_two_ranks_on_one_gpu)."""
+    import socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(NCCL_WORKER)
+    n = min(torch.cuda.device_count(), 4)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, VR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
