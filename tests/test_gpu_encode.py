@@ -227,5 +227,5 @@ def test_build_from_checkpoint_dir(tmp_path):
     torch.cuda.synchronize()
     assert abs(torch.cuda.mem_get_info()[0] - free0) < 8 << 20
     with pytest.raises(ValueError):
-        DRModelForInference.build(model_args=types.SimpleNamespace(model_name_or_path=str(ck), pooling="mean"), cfg=cfg)
+        DRModelForInference.build(model_args=types.SimpleNamespace(model_name_or_path=str(ck), pooling="drop_mean"), cfg=cfg)
     ref_enc.close(); model.encoder.close()

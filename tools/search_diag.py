@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Per-stage times (HIP events inside vr_index_search) and certification counters of the fused search for several
+batch sizes over a random unit-norm index:  python tools/search_diag.py [rows] [dim]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visrag_amd.engine import HipIndex
+
+nd = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+dim = int(sys.argv[2]) if len(sys.argv) > 2 else 2304
+g = torch.Generator(device="cuda").manual_seed(0)
+C = torch.randn((nd, dim), generator=g, device="cuda"); C /= C.norm(dim=1, keepdim=True)
+Qall = torch.randn((1000, dim), generator=g, device="cuda"); Qall /= Qall.norm(dim=1, keepdim=True)
+ix = HipIndex(dim, nd); ix.add(C)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for eps in (None, -1.0):
+    ix.set_search_eps(eps)
+    for nq in (1, 16, 64, 256, 1000):
+        Q = Qall[:nq].contiguous()
+        for _ in range(3):
+            ix.search(Q, 10)
+        ix.search_stats(reset=True)
+        e0.record()
+        for _ in range(20):
+            ix.search(Q, 10)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        st = ix.search_stats(reset=True)
+        ix.set_search_profile(True)
+        for _ in range(10):
+            ix.search(Q, 10)
+        pr = ix.get_search_profile(); ix.set_search_profile(False)
+        print(f"eps={'default' if eps is None else 'off'} nq={nq:5d}  {ms*1e3:8.1f} us/search   stages(us): " +
+              " ".join(f"{k}={v*1e3:.1f}" for k, v in pr.items() if k != "calls") + f"   per-20-calls: {st}", flush=True)

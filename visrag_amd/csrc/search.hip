@@ -228,52 +228,60 @@ __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
 #pragma unroll
         for (int w = 1; w < 4; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
         const uint64_t t = shfl_u64(wave_sort_desc(v), GD - 1);
-        if (lane == 0) { thr_s = t; n_s = 0; }
+        if (lane == 0) thr_s = t;
     }
     __syncthreads();
+    // every entry with key >= thr -> surv (<= MERGE_CAP of them), the best 64 sorted into cand; returns their number
+    auto gather = [&](uint64_t thr) -> int {
+        if (tid == 0) n_s = 0;
+        __syncthreads();
+        for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+            int id8[8];
+            float sc8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + 256 * u, total - 1);
+                id8[u] = (e0 + 256 * u < total) ? ci[e] : -1;
+                sc8[u] = cs[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (id8[u] >= 0) {
+                    const uint64_t key = make_key(sc8[u], (uint32_t)id8[u]);
+                    if (key >= thr) { const int pos = atomicAdd(&n_s, 1); if (pos < MERGE_CAP) surv[pos] = key; }
+                }
+            }
+        }
+        __syncthreads();
+        const int n = n_s;
+        if (wave == 0) {
+            uint64_t best = KEY_NONE;
+            if (n <= MERGE_CAP) {
+                for (int base = 0; base < n; base += 64) {
+                    const uint64_t key = (base + lane < n) ? surv[base + lane] : KEY_NONE;
+                    best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+                }
+            } else {                                        // massive ties: merge everything
+                for (int base = 0; base < total; base += 64) {
+                    const int e = base + lane;
+                    uint64_t key = KEY_NONE;
+                    if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
+                    best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+                }
+            }
+            cand[lane] = best;
+        }
+        __syncthreads();
+        return n;
+    };
     const uint64_t thr = thr_s;
-    for (int e0 = tid; e0 < total; e0 += 256 * 8) {
-        int id8[8];
-        float sc8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = min(e0 + 256 * u, total - 1);
-            id8[u] = (e0 + 256 * u < total) ? ci[e] : -1;
-            sc8[u] = cs[e];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (id8[u] >= 0) {
-                const uint64_t key = make_key(sc8[u], (uint32_t)id8[u]);
-                if (key >= thr) { const int pos = atomicAdd(&n_s, 1); if (pos < MERGE_CAP) surv[pos] = key; }
-            }
-        }
-    }
-    __syncthreads();
-    const int n = n_s;
-    if (wave == 0) {
-        uint64_t best = KEY_NONE;
-        if (n <= MERGE_CAP) {
-            for (int base = 0; base < n; base += 64) {
-                const uint64_t key = (base + lane < n) ? surv[base + lane] : KEY_NONE;
-                best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
-            }
-        } else {                                        // massive ties: merge everything
-            for (int base = 0; base < total; base += 64) {
-                const int e = base + lane;
-                uint64_t key = KEY_NONE;
-                if (e < total && ci[e] >= 0) key = make_key(cs[e], (uint32_t)ci[e]);
-                best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
-            }
-        }
-        cand[lane] = best;
-    }
-    __syncthreads();
+    const int n = gather(thr);
     // entries outside `cand`: below the gather bound, or (more than 64 gathered) below cand[63]
     const float coverB = n > 64 ? key_score(cand[63]) : (thr == KEY_NONE ? -INFINITY : key_score(thr));
     float dropB = drop_s ? orderable_f32(drop_s) : -INFINITY;
     if (p.thr_used) dropB = fmaxf(dropB, p.thr_used[q]);
-    certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s);
+    certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
+                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); });
 }
 
 int search_kprime(int k) {

@@ -292,43 +292,50 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
 #pragma unroll
         for (int w = 1; w < 4; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
         const uint64_t t = shfl_u64(wave_sort_desc(v), GD - 1);
-        if (lane == 0) { thr_s = t; n_s = 0; }
+        if (lane == 0) thr_s = t;
     }
     __syncthreads();
-    const uint64_t thr = thr_s;
-    for (int l = tid; l < lists; l += 256) {
-        const int c = cnts[l] & 0xFF;
-        const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)l * HL_CAP);
-        for (int e = 0; e < c; e += 2) {
-            const u64x2 a = row[e >> 1];
+    // every entry with key >= thr -> surv (<= MERGE_CAP of them), the best 64 sorted into cand; returns their number
+    auto gather = [&](uint64_t thr) -> int {
+        if (tid == 0) n_s = 0;
+        __syncthreads();
+        for (int l = tid; l < lists; l += 256) {
+            const int c = cnts[l] & 0xFF;
+            const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)l * HL_CAP);
+            for (int e = 0; e < c; e += 2) {
+                const u64x2 a = row[e >> 1];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (e + u < c && a[u] >= thr && a[u] != KEY_NONE) {
-                    const int pos = atomicAdd(&n_s, 1);
-                    if (pos < MERGE_CAP) surv[pos] = a[u];
+                for (int u = 0; u < 2; ++u) {
+                    if (e + u < c && a[u] >= thr && a[u] != KEY_NONE) {
+                        const int pos = atomicAdd(&n_s, 1);
+                        if (pos < MERGE_CAP) surv[pos] = a[u];
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    const int n = n_s;
-    if (wave == 0) {
-        uint64_t best = KEY_NONE;
-        if (n <= MERGE_CAP) {
-            for (int base = 0; base < n; base += 64) {
-                const uint64_t key = (base + lane < n) ? surv[base + lane] : KEY_NONE;
-                best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+        __syncthreads();
+        const int n = n_s;
+        if (wave == 0) {
+            uint64_t best = KEY_NONE;
+            if (n <= MERGE_CAP) {
+                for (int base = 0; base < n; base += 64) {
+                    const uint64_t key = (base + lane < n) ? surv[base + lane] : KEY_NONE;
+                    best = (base == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+                }
+            } else {
+                for (int l = 0; l < lists; ++l) {
+                    const int c = cnts[l] & 0xFF;
+                    const uint64_t key = (lane < c) ? keys[(size_t)l * HL_CAP + lane] : KEY_NONE;
+                    best = (l == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+                }
             }
-        } else {
-            for (int l = 0; l < lists; ++l) {
-                const int c = cnts[l] & 0xFF;
-                const uint64_t key = (lane < c) ? keys[(size_t)l * HL_CAP + lane] : KEY_NONE;
-                best = (l == 0) ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
-            }
+            cand[lane] = best;
         }
-        cand[lane] = best;
-    }
-    __syncthreads();
+        __syncthreads();
+        return n;
+    };
+    const uint64_t thr = thr_s;
+    const int n = gather(thr);
     // what the re-scoring does not see (search_common.h: certify_tail):
     //   list entries outside `cand`: below the gather bound, or (more than 64 gathered) below cand[63];
     //   rows that never reached a list: below the sweep's starting threshold — or, where a half-list was compacted
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     const float coverB = n > 64 ? key_score(cand[63]) : (thr == KEY_NONE ? -INFINITY : key_score(thr));
     float dropB = p.thr_used ? p.thr_used[q] : -INFINITY;
     if (comp_s && cand[KP - 1] != KEY_NONE) dropB = fmaxf(dropB, key_score(cand[KP - 1]));
-    certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s);
+    certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
+                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); });
 }
 
 template <int KP>

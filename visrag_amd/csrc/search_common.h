@@ -108,14 +108,19 @@ __device__ __forceinline__ void emit_slot(const SearchArgs& p, int q, int slot, 
 //   1. re-scores the bf16 top-KP, takes s_k and tau;
 //   2. re-scores every further gathered candidate with b >= tau (they are sorted: a prefix);
 //   3. certifies the result if everything NOT re-scored is known to lie below tau:
-//        coverB  >= b of every list entry that was not gathered into `cand`,
+//        coverB  >= b of every list entry that was not gathered into `cand` (if that bound is too high but the
+//                 lists are complete down to tau, the entries >= tau are gathered again first),
 //        dropB   >= b of every row the sweep dropped before it reached a list;
 //      otherwise the query goes on the flag list and the exact fp32 pass (search_exact.hip) redoes it.
 // cand: LDS[64], the best gathered keys sorted descending (KEY_NONE padded); exact_s: LDS[64] scratch.
+// regather(tau) -> n: gathers EVERY list entry with a score >= tau again (the first gather stopped at a bound
+// that turned out to lie above tau), leaves the best 64 of the n sorted in cand; used when the lists themselves
+// are complete down to tau (dropB < tau), so that only a query with more than 64 rows inside the error band —
+// or incomplete lists — pays for the exact pass.
 // Called by all 256 threads of the query's workgroup; cand / coverB / dropB must be visible (barrier).
-template <int KP>
+template <int KP, typename Regather>
 __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
-                                             float coverB, float dropB, float* sh_tau, int* sh_x) {
+                                             float coverB, float dropB, float* sh_tau, int* sh_x, Regather regather) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = p.dim >> 2;
     const float* qrow = p.q_f32 + (size_t)q * p.dim;
@@ -128,6 +133,7 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
         const float a = wave_sum(dot_lane(qv, p.index_f32 + (size_t)id * p.dim, nv, lane));
         if (lane == 0) exact_s[c] = make_key(a, id);
     };
+    auto below = [](float bound, float tau) { return bound == -INFINITY || bound < tau; };
     if (tid < 64) exact_s[tid] = KEY_NONE;
     __syncthreads();
     for (int c = wave; c < KP; c += 4) rescore(c);
@@ -135,7 +141,6 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
     const bool certify = p.eps_rel >= 0.f;
     if (wave == 0) {
         float tau = -INFINITY;
-        int x = 0;
         if (certify) {
             float qq = 0.f;
 #pragma unroll
@@ -144,10 +149,21 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
             const float eps = p.eps_rel * sqrtf(wave_sum(qq)) * p.dmax[0];
             const uint64_t kth = shfl_u64(wave_sort_desc(exact_s[lane]), p.k - 1);
             if (kth != KEY_NONE) tau = key_score(kth) - eps;
-            const uint64_t c = cand[lane];
-            x = __popcll(__ballot(lane >= KP && c != KEY_NONE && key_score(c) >= tau));
         }
-        if (lane == 0) { *sh_tau = tau; *sh_x = x; }
+        if (lane == 0) { *sh_tau = tau; *sh_x = (certify && !below(coverB, tau) && below(dropB, tau) && tau > -INFINITY) ? 1 : 0; }
+    }
+    __syncthreads();
+    const float tau = *sh_tau;
+    const bool again = *sh_x != 0;
+    __syncthreads();
+    if (again) {                                         // workgroup-uniform
+        const int n = regather(tau);
+        coverB = n > 64 ? key_score(cand[63]) : -INFINITY;
+    }
+    if (wave == 0) {
+        const uint64_t c = cand[lane];
+        const int x = certify ? __popcll(__ballot(lane >= KP && c != KEY_NONE && key_score(c) >= tau)) : 0;
+        if (lane == 0) *sh_x = x;
     }
     __syncthreads();
     const int x = *sh_x;
@@ -157,12 +173,9 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
         const uint64_t ex = wave_sort_desc(exact_s[lane]);
         if (lane < p.k) emit_slot(p, q, lane, ex);
         if (lane == 0) {
-            const float tau = *sh_tau;
             int what = 3;
             if (certify) {
-                const bool below_c = coverB == -INFINITY || coverB < tau;
-                const bool below_d = dropB == -INFINITY || dropB < tau;
-                what = (below_c && below_d) ? (x ? 1 : 0) : 2;
+                what = (below(coverB, tau) && below(dropB, tau)) ? ((x || again) ? 1 : 0) : 2;
                 if (what == 2 && p.flag_count) {
                     const int pos = atomicAdd(p.flag_count, 1);
                     p.flag_list[pos] = q;

@@ -6,8 +6,8 @@
 // merge workgroup.  This file redoes those queries from the fp32 index alone:
 //
 //   exact_scores_kernel   S[slot][row] = fp32 dot(query flag_list[slot], row) for every row of the
-//                         index, in the summation order of the re-scoring (dot_lane): a workgroup owns
-//                         64 rows; it keeps up to EX_QB flagged queries in LDS at a time and every wave
+//                         index, in the summation order of the re-scoring (dot_lane): a workgroup walks
+//                         blocks of 64 rows; it keeps up to EX_QB flagged queries in LDS at a time and every wave
 //                         takes 16 of the rows, a row's float4 chunks in registers.
 //   bigk_select_kernel    (search_bigk.hip, exact mode) radix-selects the top k of each score row.
 //
@@ -35,7 +35,6 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const float* __restri
     f32x4* qs = reinterpret_cast<f32x4*>(smem);                 // [EX_QB][nv]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = dim >> 2;
-    const int64_t row0 = (int64_t)blockIdx.x * EX_ROWS + wave * 16;
     for (int f0 = 0; f0 < nf; f0 += EX_QB) {
         const int nb = min(EX_QB, nf - f0);
         __syncthreads();
@@ -44,8 +43,9 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const float* __restri
             qs[b * nv + c] = reinterpret_cast<const f32x4*>(q_f32 + (size_t)flag_list[f0 + b] * dim)[c];
         }
         __syncthreads();
+        for (int64_t blk = blockIdx.x; blk * EX_ROWS < n_docs; blk += gridDim.x)
         for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + r;
+            const int64_t row = blk * EX_ROWS + wave * 16 + r;
             if (row >= n_docs) break;                             // wave-uniform
             const f32x4* dr = reinterpret_cast<const f32x4*>(index_f32 + (size_t)row * dim);
             f32x4 dv[MERGE_MAXV];
@@ -75,7 +75,8 @@ hipError_t launch_exact_scores(const float* index_f32, int64_t n_docs, int dim, 
     const int lds = EX_QB * dim * 4;
     static unsigned long long attr = 0;     // bit d: set on device d
     set_max_dynamic_lds((const void*)exact_scores_kernel, EX_QB * 64 * 4 * MERGE_MAXV * 4, attr);
-    const int64_t blocks = (n_docs + EX_ROWS - 1) / EX_ROWS;
+    int64_t blocks = (n_docs + EX_ROWS - 1) / EX_ROWS;
+    if (blocks > 512) blocks = 512;           // two workgroups per CU walk the row blocks (and leave at once when nothing is flagged)
     hipLaunchKernelGGL(exact_scores_kernel, dim3((unsigned)blocks), dim3(256), lds, s, index_f32, n_docs, dim, q_f32,
                        flag_list, flag_count, S, ldS);
     return hipGetLastError();
