@@ -60,6 +60,12 @@ template <> struct AttnCfg<72>  { static constexpr int K32 = 2, TAIL = 1, DFRAGS
 template <> struct AttnCfg<80>  { static constexpr int K32 = 2, TAIL = 1, DFRAGS = 5, PITCH = 160; };
 template <> struct AttnCfg<128> { static constexpr int K32 = 4, TAIL = 0, DFRAGS = 8, PITCH = 288; };
 
+#ifndef VR_ATTN_TAIL16
+#define VR_ATTN_TAIL16 1
+#endif
+// the tail of head_dim 72 / 80 (d = 64..79) as ONE 16x16x16 MFMA per fragment — half the matrix-pipe time of the
+// 16x16x32 form it replaces, whose second half multiplied zeros (72: 80 instead of 96 columns of QK^T work)
+constexpr bool TAIL16 = VR_ATTN_TAIL16 != 0;
 constexpr int ATT_KV = 64;          // keys per tile
 constexpr float MAX_SLACK = 8.0f;   // log2 units the running max may lag behind before O is rescaled
 
@@ -142,7 +148,15 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
         // tail MFMA (d = 64..95 window): lanes fq == 0 carry the real d = 64..71, every other k-slot of Q
         // is zero — so the K operand of those slots may be ANY finite LDS content (see scores())
         u32x4 rt = {0, 0, 0, 0};
-        if (TAIL && ok && fq < TAILQ) rt = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 8);
+        if constexpr (TAIL && TAIL16) {
+            // 16x16x16 tail: lane (fr, fq) holds Q[q = fr][d = 64 + fq*4 .. +3] in the low half (d >= HD: zero)
+            if (ok && 64 + fq * 4 < HD) {
+                const u32x2 r2 = *reinterpret_cast<const u32x2*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 4);
+                rt[0] = r2[0]; rt[1] = r2[1];
+            }
+        } else {
+            if (TAIL && ok && fq < TAILQ) rt = *reinterpret_cast<const u32x4*>(qbase + (size_t)q * p.ldq + K32 * 32 + fq * 8);
+        }
         qtail[f] = __builtin_bit_cast(bf16x8, rt);
     }
 
@@ -251,7 +265,13 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
             // tail: one b128 read per lane at d = 64 + fq*8.  fq 0: the real d 64..71; fq 1: the row's zero
             // padding; fq 2, 3: the first bytes of the NEXT row (finite K data, or the start of the next
             // slot / the V slots after the last row) — multiplied by Q's zero k-slots
-            if constexpr (TAIL) kt[kf] = *reinterpret_cast<const bf16x8*>(kr + K32 * 64);
+            if constexpr (TAIL && TAIL16) {
+                // d = 64 + fq*4 .. +3 of key row fr: 8 bytes at column byte 128 + fq*8 (72: d 72..79 is the row's zero padding)
+                const u32x2 r2 = *reinterpret_cast<const u32x2*>(kr - fq * 16 + K32 * 64 + fq * 8);
+                kt[kf] = __builtin_bit_cast(bf16x8, u32x4{r2[0], r2[1], 0u, 0u});
+            } else if constexpr (TAIL) {
+                kt[kf] = *reinterpret_cast<const bf16x8*>(kr + K32 * 64);
+            }
         }
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
@@ -264,7 +284,17 @@ __global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnA
 #pragma unroll
                 for (int f = 0; f < QF; ++f)
                     s[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kf][ks], qf[f][ks], s[f][kf], 0, 0, 0);
-        if constexpr (TAIL) {
+        if constexpr (TAIL && TAIL16) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int f = 0; f < QF; ++f) {
+                    const bf16x4 ka4 = __builtin_shufflevector(kt[kf], kt[kf], 0, 1, 2, 3);
+                    const bf16x4 qb4 = __builtin_shufflevector(qtail[f], qtail[f], 0, 1, 2, 3);
+                    s[f][kf] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ka4), __builtin_bit_cast(s16x4, qb4),
+                                                                         s[f][kf], 0, 0, 0);
+                }
+        } else if constexpr (TAIL) {
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
