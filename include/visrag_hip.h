@@ -181,9 +181,10 @@ int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k,
  * worst case by Cauchy-Schwarz); eps_rel < 0 switches certification off (the bf16 top-(k+6)
  * re-scored, as in rounds 1-2: tolerance-exact); NaN restores the default. */
 int vr_index_set_search_eps(vr_index_t ix, float eps_rel);
-/* Queries counted since the last reset: out4 = {certified at once, certified after extended
- * re-scoring, flagged and redone by the exact pass, searched with certification off}. */
-int vr_index_search_stats(vr_index_t ix, int64_t* out4, int32_t reset);
+/* Queries counted since the last reset: out5[0..4] = {certified at once, certified after extended
+ * re-scoring, flagged and redone by the exact pass, searched with certification off, of the second
+ * group: those whose candidates had to be gathered a second time}. */
+int vr_index_search_stats(vr_index_t ix, int64_t* out5, int32_t reset);
 /* Per-stage HIP-event times of vr_index_search (k <= 26), summed over calls since enabling:
  * ms5 = {query conversion, threshold pre-pass, sweep, merge + re-scoring, exact pass}.
  * While enabled every call ends with an event synchronisation. */

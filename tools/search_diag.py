@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-stage times (HIP events inside vr_index_search) and certification counters of the fused search for several
-batch sizes over a random unit-norm index:  python tools/search_diag.py [rows] [dim]"""
+batch sizes over a random unit-norm index:  python tools/search_diag.py [rows] [dim] [nq,nq,...] [certified-only]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,9 +13,10 @@ C = torch.randn((nd, dim), generator=g, device="cuda"); C /= C.norm(dim=1, keepd
 Qall = torch.randn((1000, dim), generator=g, device="cuda"); Qall /= Qall.norm(dim=1, keepdim=True)
 ix = HipIndex(dim, nd); ix.add(C)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for eps in (None, -1.0):
+NQS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 16, 64, 256, 1000]
+for eps in ((None,) if len(sys.argv) > 4 else (None, -1.0)):
     ix.set_search_eps(eps)
-    for nq in (1, 16, 64, 256, 1000):
+    for nq in NQS:
         Q = Qall[:nq].contiguous()
         for _ in range(3):
             ix.search(Q, 10)

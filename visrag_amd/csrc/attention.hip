@@ -89,7 +89,7 @@ __device__ __forceinline__ float col4_sum(float v) {
 }
 
 template <int HD, int QF, int PIPE>
-__global__ __launch_bounds__(256, PIPE == 3 ? 3 : 2) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, QF >= 4 ? 1 : (PIPE == 3 ? 3 : 2)) void attention_kernel(AttnArgs p) {
     using C = AttnCfg<HD>;
     constexpr int K32 = C::K32, DFRAGS = C::DFRAGS, PITCH = C::PITCH;
     constexpr bool TAIL = C::TAIL != 0;

@@ -1072,7 +1072,8 @@ struct vr_index_s {
     DevBuf q32, qbf, cs, ci, ck, os, oi, ok, thr, sbuf;  // query staging / candidates / outputs / thresholds / score rows
     int64_t qcap = 0, ccap = 0, kcap = 0;
     // certification state (search_common.h): word 0 = largest row norm (f32), word 1 = flag count,
-    // words 2..5 = query counters {certified at once, after extended re-scoring, flagged, uncertified mode}
+    // words 2..5 = query counters {certified at once, after extended re-scoring, flagged, uncertified mode}, word 6 = queries
+    // whose candidates were gathered a second time
     DevBuf cert, flags;
     int64_t fcap = 0;
     float eps_rel = -2.f;             // -2: the rigorous default for `dim`; < 0 otherwise: certification off
@@ -1148,14 +1149,14 @@ extern "C" int vr_index_set_search_eps(vr_index_t ix, float eps_rel) {
     return VR_OK;
 }
 
-extern "C" int vr_index_search_stats(vr_index_t ix, int64_t* out4, int32_t reset) {
+extern "C" int vr_index_search_stats(vr_index_t ix, int64_t* out4, int32_t reset) {     // out4: FIVE words, see the header
     if (!ix || !out4) return fail(VR_ERR_INVALID, "NULL argument");
     VRCHK(set_dev(ix->device));
     HIPCHK(hipDeviceSynchronize());
-    unsigned w[4];
-    HIPCHK(hipMemcpy(w, ix->cert.as<unsigned>() + 2, 16, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) out4[i] = w[i];
-    if (reset) HIPCHK(hipMemset(ix->cert.as<unsigned>() + 2, 0, 16));
+    unsigned w[5];
+    HIPCHK(hipMemcpy(w, ix->cert.as<unsigned>() + 2, 20, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; ++i) out4[i] = w[i];
+    if (reset) HIPCHK(hipMemset(ix->cert.as<unsigned>() + 2, 0, 20));
     return VR_OK;
 }
 

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict
 // sweep's starting threshold.
 template <int KP>
 __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
-    constexpr int GD = KP + 16 < 64 ? KP + 16 : 64;
+    constexpr int GD = KP + MERGE_GD_EXTRA < 64 ? KP + MERGE_GD_EXTRA : 64;
     __shared__ uint64_t lm[256];
     __shared__ uint64_t surv[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];

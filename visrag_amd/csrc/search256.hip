@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void search_sweep256_kernel(SearchArgs p, int 
 // behind a chain of dependent loads with a few hundred queries (128 queries: 101 us).
 template <int KP>
 __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
-    constexpr int GD = KP + 16 < 64 ? KP + 16 : 64;   // gather depth: certification may want candidates past the KP-th
+    constexpr int GD = KP + MERGE_GD_EXTRA < 64 ? KP + MERGE_GD_EXTRA : 64;   // gather depth: certification may want candidates past the KP-th
     __shared__ uint64_t lm[256];
     __shared__ uint64_t surv[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];

@@ -48,6 +48,12 @@ __device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fres
 
 constexpr int MERGE_MAXV = 10;     // dim <= 64 * 4 * MERGE_MAXV
 constexpr int MERGE_CAP = 256;     // survivor buffer per query (merge kernels)
+#ifndef VR_MERGE_GD
+#define VR_MERGE_GD 16
+#endif
+// gather depth of the merge kernels beyond KP: the first gather keeps every list entry above (a lower bound of) the
+// (KP + MERGE_GD_EXTRA)-th best key — deep enough that the certification rarely has to gather again
+constexpr int MERGE_GD_EXTRA = VR_MERGE_GD;
 
 // ---- exact fp32 scores ------------------------------------------------------------------------
 // ONE definition of the fp32 dot product behind every score the library returns: lane l owns the
@@ -157,6 +163,7 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
     const bool again = *sh_x != 0;
     __syncthreads();
     if (again) {                                         // workgroup-uniform
+        if (tid == 0 && p.stats) atomicAdd(&p.stats[4], 1u);
         const int n = regather(tau);
         coverB = n > 64 ? key_score(cand[63]) : -INFINITY;
     }

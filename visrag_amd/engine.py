@@ -270,10 +270,10 @@ class HipIndex:
         _lib.check(self.lib.vr_index_set_search_eps(self._h, float("nan") if eps_rel is None else float(eps_rel)))
 
     def search_stats(self, reset: bool = False) -> Dict[str, int]:
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 5)()
         _lib.check(self.lib.vr_index_search_stats(self._h, out, 1 if reset else 0))
         return {"certified": int(out[0]), "certified_extended": int(out[1]), "exact_pass": int(out[2]),
-                "uncertified": int(out[3])}
+                "uncertified": int(out[3]), "regathered": int(out[4])}
 
     SEARCH_STAGES = ("convert", "thresholds", "sweep", "merge", "exact_pass")
 
