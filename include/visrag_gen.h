@@ -69,6 +69,14 @@ int vg_vision_create(vg_model_t m, const vg_vision_config_t* cfg);
  * The embeddings also stay on the device: a vg_prefill with embeds == NULL and n_embed == rows / merge^2 uses them. */
 int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t* grid_thw, int32_t n_images, float* embeds_out,
                      void* stream);
+/* The same with the image processor's rescale / normalise / patchify done on the device: pages[i] is an 8-bit RGB (HWC)
+ * image of exactly (grid_h * patch_size) x (grid_w * patch_size) pixels — the page already resized to smart_resize's size,
+ * e.g. by vr_resize_bicubic (Pillow-exact) — all on the host or all on the device; mean3 / std3 are the processor's
+ * image_mean / image_std (host).  Element (c, t, y, x) of a patch row = (u8 / 255 - mean[c]) / std[c] in fp32, rounded to
+ * bf16 — what the reference's processor + bf16 tower input amount to (predict.py:140; 0.6 MB per 448 x 448 page over the
+ * boundary instead of 4.8 MB of f32 rows).  Still images only (t = 1). */
+int vg_vision_encode_pages(vg_model_t m, const uint8_t* const* pages, int32_t pages_on_device, const float* mean3,
+                           const float* std3, const int32_t* grid_thw, int32_t n_images, float* embeds_out, void* stream);
 /* Host-only (no GPU needed): the tower's token geometry for a set of grids — tests.  order [tokens]: the image token at
  * window-order place i; win_bounds [n_windows + 1]: patch-row boundaries of the attention windows in that order;
  * hw [rows][2]: patch coordinates of every pixel row.  Any output may be NULL. */

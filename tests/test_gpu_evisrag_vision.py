@@ -192,3 +192,30 @@ def test_llm_from_checkpoint_directory_with_text_prompt(setup, tmp_path):
     assert out.prompt_token_ids == ref.prompt_token_ids
     assert out.outputs[0].token_ids == ref.outputs[0].token_ids
     assert out.outputs[0].text == " ".join(f"w{t}" for t in out.outputs[0].token_ids if t >= 8)
+
+
+def test_pages_processed_on_the_gpu_equal_the_host_processor(setup):
+    """vg_vision_encode_pages (Pillow-exact GPU resize + rescale / normalise / patchify inside the tower call) against the
+    host image processor restatement (process_images: PIL resize + numpy) feeding vg_vision_encode: same bf16 patch
+    rows, hence the same embedding rows; and generate() with PIL pages takes the GPU path by default."""
+    from PIL import Image
+    from visrag_amd.evisrag import process_images, process_pages_gpu
+    g, cfg, vcfg, llm = setup
+    rng = np.random.default_rng(7)
+    pages = [Image.fromarray(rng.integers(0, 256, size=s + (3,), dtype=np.uint8)) for s in ((60, 90), (200, 130), (56, 56), (84, 112))]
+    px, grid = process_images(pages, llm.vision)
+    host = llm.encode_images(px, grid)
+    dev_pages, grid2 = process_pages_gpu(pages, llm.vision, llm.device)
+    assert np.array_equal(grid, grid2)
+    assert all(t.is_cuda and t.dtype == torch.uint8 for t in dev_pages)
+    dev = llm.encode_pages(dev_pages, grid2)
+    assert dev.shape == host.shape
+    scale = np.abs(host).max()
+    assert np.abs(dev - host).max() < 2e-3 * scale, (np.abs(dev - host).max(), scale)
+    assert (np.abs(dev - host).max(axis=1) == 0).mean() > 0.9            # bit-identical rows but for stray 1-ulp divisions
+    # a page already at its processed size, handed over as a cuda tensor, is used in place
+    t = torch.from_numpy(np.asarray(pages[2])).cuda()
+    again, _ = process_pages_gpu([t], llm.vision, llm.device)
+    assert again[0].data_ptr() == t.data_ptr()
+    with pytest.raises(ValueError):
+        llm.encode_pages([dev_pages[0]], grid2[1:2])

@@ -106,6 +106,7 @@ GEN_SIGNATURES = {
     "vg_run_end": (C.c_int, [_vp]),
     "vg_vision_create": (C.c_int, [_vp, C.POINTER(VGVisionConfig)]),
     "vg_vision_encode": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "vg_vision_encode_pages": (C.c_int, [_vp, C.POINTER(_vp), _i32, C.POINTER(_f32), C.POINTER(_f32), _vp, _i32, _vp, _vp]),
     "vg_vision_plan": (C.c_int, [C.POINTER(VGVisionConfig), _vp, _i32, _vp, _vp, C.POINTER(_i32), _vp]),
 }
 

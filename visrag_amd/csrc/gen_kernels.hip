@@ -264,6 +264,36 @@ hipError_t launch_gather_rows_bf16(const float* src, const int* row_idx, int n, 
     return hipGetLastError();
 }
 
+// The image processor + the row mover in one pass (vg_vision_encode_pages): row i of dst = the bf16 patch row of
+// patch (ph[i], pw[i]) of page img[i] — element (c, t, y, x) = (u8 / 255 - mean[c]) / std[c] in fp32 like the processor
+// (rescale, normalise), the still image repeated over the temporal patch — columns [3 * tp * P * P, ld) zero.
+struct PatchNorm { float mean[3], std[3]; };
+__global__ void patch_rows_u8_kernel(const uint8_t* const* __restrict__ pages, const int* __restrict__ page_w,
+                                     const int* __restrict__ img, const int* __restrict__ ph, const int* __restrict__ pw, int P,
+                                     int tp, PatchNorm nm, bf16_t* __restrict__ dst, int ld) {
+    const int i = blockIdx.x;
+    const int im = img[i], W = page_w[im];
+    const uint8_t* base = pages[im] + ((size_t)ph[i] * P * W + (size_t)pw[i] * P) * 3;
+    const int pp = P * P, dim = 3 * tp * pp;
+    for (int e = threadIdx.x; e < ld; e += blockDim.x) {
+        float v = 0.f;
+        if (e < dim) {
+            const int c = e / (tp * pp), rem = e % pp, y = rem / P, x = rem % P;
+            const float px = (float)base[((size_t)y * W + x) * 3 + c];
+            v = (px * (1.0f / 255.0f) - nm.mean[c]) / nm.std[c];
+        }
+        dst[(size_t)i * ld + e] = f2bf(v);
+    }
+}
+hipError_t launch_patch_rows_u8(const uint8_t* const* pages, const int* page_w, const int* img, const int* ph, const int* pw, int n,
+                                int P, int tp, const float* mean3, const float* std3, void* dst, int ld, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    PatchNorm nm;
+    for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.std[c] = std3[c]; }
+    hipLaunchKernelGGL(patch_rows_u8_kernel, dim3(n), dim3(256), 0, s, pages, page_w, img, ph, pw, P, tp, nm, (bf16_t*)dst, ld);
+    return hipGetLastError();
+}
+
 // one decode step's attention was run as S independent KV ranges (attention_kernel with q_shared): merge them
 __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, const float* __restrict__ lse, int S, int heads,
                                     bf16_t* __restrict__ out, const int* __restrict__ S_dev) {

@@ -58,6 +58,7 @@ struct VisionTower {
     Linear mlp0, mlp2;
     DevBuf inv_freq;
     DevBuf w_pix, w_px, w_x, w_xn, w_qkv, w_cs, w_att, w_act, w_mid, w_out, w_perm, w_pos, w_cuw, w_cui, w_order;
+    DevBuf w_rowimg, w_pageptr;      // page input: image of every window-ordered row; page pointers + widths
 };
 
 // The window order of HF's get_vision_window_index (transformers/vision_utils.py:130-188) and the (h, w) coordinates of
@@ -261,9 +262,33 @@ int vision_check_complete(const vg_model_s* m) {
     return VR_OK;
 }
 
+// pixels != NULL: the processor's f32 pixel rows (host); else `pages`: n_images u8 RGB (HWC) images of exactly
+// (grid_h * patch) x (grid_w * patch) pixels, all on the host or all on the device, normalised with (mean, std) here
+static int vision_encode_impl(vg_model_t m, const float* pixels, const uint8_t* const* pages, int pages_on_device,
+                              const float* mean3, const float* std3, const int32_t* grid_thw, int32_t n_images,
+                              float* embeds_out, void* stream);
+
 extern "C" int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t* grid_thw, int32_t n_images, float* embeds_out,
                                 void* stream) {
-    if (!m || !pixels || !grid_thw) return fail(VR_ERR_INVALID, "NULL argument");
+    if (!pixels) return fail(VR_ERR_INVALID, "NULL argument");
+    return vision_encode_impl(m, pixels, nullptr, 0, nullptr, nullptr, grid_thw, n_images, embeds_out, stream);
+}
+
+extern "C" int vg_vision_encode_pages(vg_model_t m, const uint8_t* const* pages, int32_t pages_on_device, const float* mean3,
+                                      const float* std3, const int32_t* grid_thw, int32_t n_images, float* embeds_out,
+                                      void* stream) {
+    if (!pages || !mean3 || !std3) return fail(VR_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < n_images; ++i)
+        if (!pages[i]) return fail(VR_ERR_INVALID, "page %d is NULL", i);
+    for (int c = 0; c < 3; ++c)
+        if (!(std3[c] > 0.f)) return fail(VR_ERR_INVALID, "image_std must be positive");
+    return vision_encode_impl(m, nullptr, pages, pages_on_device, mean3, std3, grid_thw, n_images, embeds_out, stream);
+}
+
+static int vision_encode_impl(vg_model_t m, const float* pixels, const uint8_t* const* pages, int pages_on_device,
+                              const float* mean3, const float* std3, const int32_t* grid_thw, int32_t n_images,
+                              float* embeds_out, void* stream) {
+    if (!m || !grid_thw) return fail(VR_ERR_INVALID, "NULL argument");
     if (!m->vis) return fail(VR_ERR_STATE, "no vision tower (vg_vision_create)");
     if (!m->finalized) return fail(VR_ERR_STATE, "vg_finalize has not succeeded");
     if (m->running) return fail(VR_ERR_STATE, "a free run is in progress (vg_run_end first)");
@@ -286,11 +311,58 @@ extern "C" int vg_vision_encode(vg_model_t m, const float* pixels, const int32_t
     HIPCHK(hipMemcpyAsync(v->w_cuw.p, p.win_bounds.data(), p.win_bounds.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(v->w_cui.p, p.img_bounds.data(), p.img_bounds.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(v->w_order.p, p.order.data(), (size_t)NT * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(v->w_pix.p, pixels, (size_t)R * v->PD * 4, hipMemcpyHostToDevice, s));
+    std::vector<int> row_img;                         // pages path: image of every permuted row
+    std::vector<const uint8_t*> page_dev;
+    std::vector<int> page_w;
+    if (pixels) {
+        HIPCHK(hipMemcpyAsync(v->w_pix.p, pixels, (size_t)R * v->PD * 4, hipMemcpyHostToDevice, s));
+    } else {
+        if (v->c.in_channels != 3) return fail(VR_ERR_INVALID, "page input needs a 3-channel tower");
+        // rows of image i in processor order: [img_bounds[i], img_bounds[i+1]) (still images: one frame each)
+        row_img.resize(R);
+        std::vector<int> owner(R);
+        for (int i = 0, r = 0; i < n_images; ++i) {
+            if (grid_thw[3 * i] != 1) return fail(VR_ERR_INVALID, "page input is for still images (t = 1)");
+            for (int k = 0; k < grid_thw[3 * i + 1] * grid_thw[3 * i + 2]; ++k) owner[r++] = i;
+        }
+        for (int r = 0; r < R; ++r) row_img[r] = owner[perm[r]];
+        page_dev.resize(n_images); page_w.resize(n_images);
+        size_t total = 0;
+        std::vector<size_t> off(n_images);
+        const int P = v->c.patch_size;
+        for (int i = 0; i < n_images; ++i) {
+            page_w[i] = grid_thw[3 * i + 2] * P;
+            off[i] = total;
+            total += ((size_t)grid_thw[3 * i + 1] * P * page_w[i] * 3 + 15) / 16 * 16;
+        }
+        if (pages_on_device) {
+            for (int i = 0; i < n_images; ++i) page_dev[i] = pages[i];
+        } else {
+            // (w_pix holds max_rows f32 pixel rows: 4 bytes per u8 the pages can have)
+            if (total > v->w_pix.bytes) return fail(VR_ERR_CAPACITY, "pages exceed the pixel staging buffer");
+            for (int i = 0; i < n_images; ++i) {
+                const size_t nb = (size_t)grid_thw[3 * i + 1] * P * page_w[i] * 3;
+                HIPCHK(hipMemcpyAsync((char*)v->w_pix.p + off[i], pages[i], nb, hipMemcpyHostToDevice, s));
+                page_dev[i] = (const uint8_t*)v->w_pix.p + off[i];
+            }
+        }
+        VRCHK(v->w_rowimg.reserve((size_t)R * 4));
+        VRCHK(v->w_pageptr.reserve((size_t)n_images * 8 + (size_t)n_images * 4 + 32));
+        HIPCHK(hipMemcpyAsync(v->w_rowimg.p, row_img.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(v->w_pageptr.p, page_dev.data(), (size_t)n_images * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync((char*)v->w_pageptr.p + (size_t)n_images * 8, page_w.data(), (size_t)n_images * 4, hipMemcpyHostToDevice, s));
+    }
     HIPCHK(hipStreamSynchronize(s));                  // the host vectors above go away with this frame
     HIPCHK(launch_rope2d_table(v->w_pos.as<int>(), v->w_pos.as<int>() + R, R, v->hd / 4, v->inv_freq.as<float>(), v->w_cs.p, s));
     // ---- patch embedding over the permuted bf16 pixel rows
-    HIPCHK(launch_gather_rows_bf16(v->w_pix.as<float>(), v->w_perm.as<int>(), R, v->PD, v->w_px.p, v->PDp, s));
+    if (pixels) {
+        HIPCHK(launch_gather_rows_bf16(v->w_pix.as<float>(), v->w_perm.as<int>(), R, v->PD, v->w_px.p, v->PDp, s));
+    } else {
+        // u8 page -> /255, normalise -> bf16 patch row, straight into window order (what the processor + the row mover do)
+        HIPCHK(launch_patch_rows_u8((const uint8_t* const*)v->w_pageptr.p, (const int*)((const char*)v->w_pageptr.p + (size_t)n_images * 8),
+                                    v->w_rowimg.as<int>(), v->w_pos.as<int>(), v->w_pos.as<int>() + R, R, v->c.patch_size,
+                                    v->c.temporal_patch_size, mean3, std3, v->w_px.p, v->PDp, s));
+    }
     float* x = v->w_x.as<float>();
     { GemmArgs a = gen_gemm_args(v->w_px.p, v->PDp, v->patch, R, x, Hp); HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s)); }
     const float eps = v->c.rms_norm_eps;

@@ -111,6 +111,9 @@ hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float p
 hipError_t launch_scatter_rows(const float* src, const int* row_idx, int n, int dim, float* dst, int ld, hipStream_t s);
 // dst[i][:] = bf16(src[row_idx[i]][0..dim)), zero up to ld (src rows are dense: stride dim)
 hipError_t launch_gather_rows_bf16(const float* src, const int* row_idx, int n, int dim, void* dst, int ld, hipStream_t s);
+// dst[i][:] = bf16 patch row (c, t, y, x) of patch (ph[i], pw[i]) of u8 HWC page img[i], (u8 / 255 - mean) / std; zero up to ld
+hipError_t launch_patch_rows_u8(const uint8_t* const* pages, const int* page_w, const int* img, const int* ph, const int* pw, int n,
+                                int P, int tp, const float* mean3, const float* std3, void* dst, int ld, hipStream_t s);
 // out[h*128 + d] = sum_s 2^(lse[s][h] - max) * part[s][h*128 + d] / sum_s 2^(lse[s][h] - max): merges the S partial
 // attention rows (bf16 [S][ldp], each normalised over its own KV range) of one decode step
 hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s,

@@ -374,6 +374,31 @@ def process_images(images, vc: "VisionConfig") -> Tuple[np.ndarray, np.ndarray]:
     return np.ascontiguousarray(np.concatenate(rows), dtype=np.float32), np.asarray(grids, dtype=np.int32)
 
 
+def process_pages_gpu(images, vc: "VisionConfig", device: int = 0):
+    """The device half of process_images: every page (PIL image, u8 HWC array or cuda tensor) -> u8 HWC cuda tensor at
+    smart_resize's size (Pillow-exact bicubic on the GPU: vr_resize_bicubic; a page already at that size is only
+    uploaded) + image_grid_thw.  Rescale / normalise / patchify happen inside vg_vision_encode_pages."""
+    import torch
+    from .gpu_resize import resize_bicubic
+    p, m = vc.patch_size, vc.spatial_merge_size
+    pages, grids = [], []
+    for im in images:
+        if isinstance(im, torch.Tensor):
+            a = im
+            h, w = int(a.shape[0]), int(a.shape[1])
+        else:
+            a = np.ascontiguousarray(np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8))
+            h, w = a.shape[:2]
+        H, W = smart_resize(h, w, p * m, vc.min_pixels, vc.max_pixels)
+        if (H, W) == (h, w):
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(a).to(f"cuda:{device}")
+        else:
+            t = resize_bicubic(a, (W, H), device)
+        pages.append(t.contiguous())
+        grids.append((1, H // p, W // p))
+    return pages, np.asarray(grids, dtype=np.int32)
+
+
 def vision_weight_specs(vc: "VisionConfig"):
     """HF state-dict keys of the vision tower -> (shape, amplitude, offset) of the synthetic weights (benchmarks)."""
     import math
@@ -493,6 +518,7 @@ class LLM:
             raise TypeError("model: a checkpoint directory or a GenConfig (+ weights=iterable of (name, tensor))")
         self.cfg: GenConfig = model
         self.max_images = (limit_mm_per_prompt or {"image": 5}).get("image", 5)
+        self.gpu_images = True          # generate(): PIL pages are resized / normalised / patchified on the GPU
         self.device = int(device)
         self.detokenize = detokenize
         self.max_model_len, self.max_prefill = int(max_model_len), int(min(max_prefill, max_model_len))
@@ -558,6 +584,27 @@ class LLM:
                                               C.c_void_p(out.ctypes.data) if fetch else None, None), "vg_vision_encode")
         return out
 
+    def encode_pages(self, pages, image_grid_thw: np.ndarray, fetch: bool = True) -> Optional[np.ndarray]:
+        """The tower on u8 pages resident on the device (process_pages_gpu): the processor's rescale / normalise / patchify
+        run inside the library (vg_vision_encode_pages)."""
+        if self.vision is None:
+            raise RuntimeError("this LLM has no vision tower (LLM(..., vision=VisionConfig()))")
+        g = np.ascontiguousarray(image_grid_thw, dtype=np.int32).reshape(-1, 3)
+        p = self.vision.patch_size
+        for t, (_, gh, gw) in zip(pages, g):
+            if tuple(t.shape) != (gh * p, gw * p, 3) or not t.is_cuda or t.dtype != __import__("torch").uint8:
+                raise ValueError(f"page {tuple(t.shape)} does not match its grid {gh} x {gw} (u8 HWC cuda tensors)")
+        rows = int((g[:, 0] * g[:, 1] * g[:, 2]).sum())
+        ptrs = (C.c_void_p * len(pages))(*[t.data_ptr() for t in pages])
+        mean = (C.c_float * 3)(*self.vision.image_mean)
+        std = (C.c_float * 3)(*self.vision.image_std)
+        out = np.empty((rows // self.vision.spatial_merge_size ** 2, self.cfg.hidden_size), dtype=np.float32) if fetch else None
+        import torch
+        stream = C.c_void_p(int(torch.cuda.current_stream(self.device).cuda_stream))
+        _lib.check(self._lib.vg_vision_encode_pages(self._h, ptrs, 1, mean, std, C.c_void_p(g.ctypes.data), len(g),
+                                                    C.c_void_p(out.ctypes.data) if fetch else None, stream), "vg_vision_encode_pages")
+        return out
+
     def expand_image_tokens(self, ids: Sequence[int], token_counts: Sequence[int]) -> List[int]:
         """One placeholder per image (the chat template's <|image_pad|>) -> one per image token, like the processor does;
         ids that already hold sum(token_counts) placeholders pass through."""
@@ -576,8 +623,9 @@ class LLM:
                 out.append(t)
         return out
 
-    def prefill_images(self, ids: Sequence[int], pixel_values: np.ndarray, image_grid_thw: np.ndarray) -> Tuple[np.ndarray, List[int]]:
-        """Tower + prefill with the embedding rows staying on the device.  Returns (positions, expanded ids)."""
+    def prefill_images(self, ids: Sequence[int], pixel_values, image_grid_thw: np.ndarray) -> Tuple[np.ndarray, List[int]]:
+        """Tower + prefill with the embedding rows staying on the device.  Returns (positions, expanded ids).
+        pixel_values: the processor's f32 rows, or a list of u8 cuda pages (process_pages_gpu)."""
         c, m = self.cfg, self.vision.spatial_merge_size
         g = np.ascontiguousarray(image_grid_thw, dtype=np.int32).reshape(-1, 3)
         if len(g) > self.max_images:
@@ -586,7 +634,10 @@ class LLM:
         if any(int(t) != 1 for t, _, _ in g):
             raise ValueError("still images only (predict.py:116 sets the video limit to 0)")
         ids = self.expand_image_tokens(ids, [h * w for h, w in grids])
-        self.encode_images(pixel_values, g, fetch=False)
+        if isinstance(pixel_values, (list, tuple)):
+            self.encode_pages(pixel_values, g, fetch=False)
+        else:
+            self.encode_images(pixel_values, g, fetch=False)
         ids_a = np.ascontiguousarray(ids, dtype=np.int32)
         pos3 = np.ascontiguousarray(rope_index(list(ids_a), c.image_token_id, grids), dtype=np.int32)
         rows = np.nonzero(ids_a == c.image_token_id)[0].astype(np.int32)
@@ -702,8 +753,10 @@ class LLM:
             if images is not None or mm.get("pixel_values") is not None:
                 if self.vision is None:
                     raise RuntimeError("images need a vision tower: LLM(..., vision=VisionConfig())")
+                # PIL pages: resize on the GPU (Pillow-exact), rescale / normalise / patchify inside the tower call;
+                # processor output handed in by the caller (pixel_values) is used as it is
                 px, grid = (mm["pixel_values"], mm["image_grid_thw"]) if mm.get("pixel_values") is not None \
-                    else process_images(images, self.vision)
+                    else (process_pages_gpu(images, self.vision, self.device) if self.gpu_images else process_images(images, self.vision))
                 m2 = self.vision.spatial_merge_size ** 2
                 g = np.asarray(grid).reshape(-1, 3)
                 n_tok = int((g[:, 0] * g[:, 1] * g[:, 2]).sum()) // m2
