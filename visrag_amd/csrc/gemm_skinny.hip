@@ -34,8 +34,12 @@ constexpr int SK_W_AUX = VR_SKINNY_W_AUX;
 
 // SWIGLU (ksplit 1 only): W rows interleaved in blocks of 16 ([16 gate | 16 up | ...], EPI_SWIGLU's layout); the tile's
 // epilogue writes act = silu(gate) * up as bf16 [M][ldo] — no fp32 plane, no swiglu_sum launch.
-template <bool SWIGLU>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+// COMBINE (the decode step's o projection; M = 1, at most SK_STAGES K-steps per workgroup): A is not read from memory —
+// row 0 of every K-step's A stage is built in the prologue from the partial attention rows of the step's KV ranges,
+//     A[col] = sum_s 2^(lse_s - max) part_s[col] / sum_s 2^(lse_s - max)   per query head (attn_combine_kernel's sum; layout: kernels.h)
+// one lane per column, one wave per K-step: the launch that used to merge the ranges is gone.
+template <bool SWIGLU, bool COMBINE>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyCombine cb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = (p.N + 255) / 256;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
@@ -62,15 +66,55 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
         for (int d = 0; d < 8; ++d)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(st + wave * 8192 + d * 1024), 16, lofW + kb, sW0 + d * rgW, 0, SK_W_AUX);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(st + SK_W_BYTES + (wave & 1) * 1024), 16, lofA + kb, sA0, 0, 0);
+        if constexpr (!COMBINE)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(st + SK_W_BYTES + (wave & 1) * 1024), 16, lofA + kb, sA0, 0, 0);
     };
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // COMBINE: the partial rows and their log-sum-exps are requested BEFORE the weight stream (loads return in order: asked
+    // for after it, they would wait behind three K-steps of weights), merged while the weights are in flight
+    float cl[GEN_ATT_SPLITS], cpv[GEN_ATT_SPLITS];
+    int cS = 0;
+    if constexpr (COMBINE) {
+        cS = cb.S_dev ? *cb.S_dev : cb.S;
+        const int col = (int)kof + min(wave, max(nk - 1, 0)) * GEMM_BK + lane, h = col >> 7, d = col & 127;
+        const int kvh = cb.heads / cb.group, hkv = h / cb.group, g = h % cb.group;
+        // (unconditional loads at a clamped range index: sixteen independent requests in flight, not sixteen round trips)
+#pragma unroll
+        for (int t = 0; t < GEN_ATT_SPLITS; ++t) {
+            const int r = (min(t, max(cS - 1, 0)) * cb.group + g) * kvh + hkv;
+            cl[t] = cb.lse[r];
+            cpv[t] = bf2f(((const bf16_t*)cb.part)[(size_t)r * 128 + d]);
+        }
+#pragma unroll
+        for (int t = 0; t < GEN_ATT_SPLITS; ++t)
+            if (t >= cS) cl[t] = -INFINITY;
+    }
+    if constexpr (COMBINE) __builtin_amdgcn_sched_barrier(0);        // (hipcc would hoist the weight requests above them)
     issue(0); issue(1); issue(2);
+    if constexpr (COMBINE) {
+        // wave w builds row 0 of K-step w's A stage (nk <= SK_STAGES: every step has its own stage, nothing recycles it);
+        // rows 1..15 of the stage belong to output rows that are never stored
+        if (wave < nk) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < GEN_ATT_SPLITS; ++t) mx = fmaxf(mx, cl[t]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int t = 0; t < GEN_ATT_SPLITS; ++t) {
+                const float w = exp2f(cl[t] - mx);              // (ranges past the last: 2^-inf = 0)
+                num += w * cpv[t];
+                den += w;
+            }
+            *reinterpret_cast<bf16_t*>(smem + wave * SK_STAGE + SK_W_BYTES + lane * 2) = f2bf(num / den);
+        }
+        // (the first barrier of the loop below orders these LDS writes before every wave's reads)
+    }
     const int ch0 = (fq ^ (fr & 7)) << 4, ch1 = ((4 + fq) ^ (fr & 7)) << 4;
     for (int kt = 0; kt < nk; ++kt) {
-        VR_WAIT_VM_BARRIER(18);                     // K-step kt has landed everywhere; everyone is done with stage (kt - 1) % 4
+        if constexpr (COMBINE) { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+        else { VR_WAIT_VM_BARRIER(18); }            // K-step kt has landed everywhere; everyone is done with stage (kt - 1) % 4
         issue(kt + 3);
         const char* st = smem + (kt & (SK_STAGES - 1)) * SK_STAGE;
         const char* wr = st + (wave * 64 + fr) * 128;
@@ -122,20 +166,30 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 
 // fp32 planes out[split][M][ldo]; M <= 16 (A and W rows readable up to 16 / the next multiple of 256), K % 64 == 0; split s
 // covers K-steps [s * ceil(steps / ksplit), ...) — a split past the end writes a plane of zeros (+ bias for split 0)
-hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu) {
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu, const SkinnyCombine* combine) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
     if (a.M <= 0) return hipSuccess;
+    if (combine) {
+        // one row, every workgroup's K range inside the stage ring, columns = heads x 128
+        const int nk_all = a.K / GEMM_BK, per = (nk_all + ks - 1) / ks;
+        if (swiglu || a.M != 1 || per > SK_STAGES || a.K != combine->heads * 128 || a.K % GEMM_BK || combine->group <= 0 ||
+            combine->heads % combine->group) return hipErrorInvalidValue;
+    }
     if (swiglu && (ks != 1 || a.N % 32)) return hipErrorInvalidValue;
     if (a.M > 16 || a.N % 4 || a.K % GEMM_BK || a.rowmap || a.rowbias) return hipErrorInvalidValue;
     const size_t tn = (a.N + 255) / 256;
     if (tn * 256 * (size_t)a.ldw * 2 >= (1ull << 31) || 16 * (size_t)a.lda * 2 >= (1ull << 31)) return hipErrorInvalidValue;
     static unsigned long long attr = 0, attr_sw = 0;     // bit d: set on device d
-    if (swiglu) {
-        set_max_dynamic_lds((const void*)gemm_skinny_kernel<true>, SK_SMEM, attr_sw);
-        hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3((unsigned)tn), dim3(256), SK_SMEM, s, a);
+    static unsigned long long attr_cb = 0;
+    if (combine) {
+        set_max_dynamic_lds((const void*)gemm_skinny_kernel<false, true>, SK_SMEM, attr_cb);
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a, *combine);
+    } else if (swiglu) {
+        set_max_dynamic_lds((const void*)gemm_skinny_kernel<true, false>, SK_SMEM, attr_sw);
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), dim3((unsigned)tn), dim3(256), SK_SMEM, s, a, SkinnyCombine{});
     } else {
-        set_max_dynamic_lds((const void*)gemm_skinny_kernel<false>, SK_SMEM, attr);
-        hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a);
+        set_max_dynamic_lds((const void*)gemm_skinny_kernel<false, false>, SK_SMEM, attr);
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a, SkinnyCombine{});
     }
     return hipGetLastError();
 }

@@ -228,12 +228,16 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
         a.q = m->w_q.p; a.ldq = QD; a.k = m->kc[l].p; a.ldk = m->KVD; a.v = m->vc[l].p; a.ldv = m->KVD;
         a.heads = m->H; a.head_dim = 128; a.scale = 1.0f / sqrtf(128.0f); a.kv_group = m->H / m->KV;
         if (decode) {
+            // the G = H / KV query heads that share a KV head are the ROWS of one tile (q_head_stride): a KV range is read
+            // once per group instead of once per query head, on KV x ranges workgroups
+            const int G = m->H / m->KV;
             GenState* st = m->w_state.as<GenState>();
             a.cu_q = st->cu_q; a.cu_kv = st->cu_kv;
-            a.out = m->w_attp.p; a.ldo = QD; a.B = GEN_ATT_SPLITS; a.max_q = 1; a.causal = 0; a.q_shared = 1;
+            a.heads = m->KV; a.kv_group = 1; a.ldq = 128; a.q_head_stride = G * 128;
+            a.out = m->w_attp.p; a.ldo = m->KVD; a.B = GEN_ATT_SPLITS; a.max_q = G; a.causal = 0; a.q_shared = 1;
             a.lse = m->w_lse.as<float>();
             HIPCHK(launch_attention(a, s));
-            HIPCHK(launch_attn_combine(m->w_attp.p, QD, m->w_lse.as<float>(), 0, m->H, m->w_att.p, s, &st->splits));
+            // (the ranges are merged by the o projection below as it builds its A row: no launch of its own)
         } else {
             a.cu_q = cu; a.cu_kv = cu + 2;
             a.out = m->w_att.p; a.ldo = QD; a.B = 1; a.max_q = T; a.causal = 1; a.q_shared = 0;
@@ -245,7 +249,16 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
         GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, T, part, E);
         a.ksplit = choose_ksplit(E, QD, VR_KS_O);
         a.split_stride = (size_t)E * T;
-        HIPCHK(launch_gemm_skinny(a, s));
+        const int per = (QD / 64 + a.ksplit - 1) / a.ksplit;
+        if (T == 1 && per <= 4) {
+            GenState* st = m->w_state.as<GenState>();
+            SkinnyCombine cb{m->w_attp.p, m->w_lse.as<float>(), 0, m->H, m->H / m->KV, &st->splits};
+            HIPCHK(launch_gemm_skinny(a, s, false, &cb));
+        } else {                                    // (a K range longer than the stage ring: merge with its own launch)
+            GenState* st = m->w_state.as<GenState>();
+            HIPCHK(launch_attn_combine(m->w_attp.p, m->w_lse.as<float>(), 0, m->H, m->H / m->KV, m->w_att.p, s, &st->splits));
+            HIPCHK(launch_gemm_skinny(a, s));
+        }
         HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, a.ksplit, (size_t)E * T, E, 1.0f, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
     } else {
         GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, T, h, E);
@@ -345,7 +358,7 @@ extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int
 static int enqueue_decode(vg_model_s* m, hipStream_t s, bool sampled, float temperature, float penalty, unsigned long long seed) {
     const int E = m->E;
     GenState* st = m->w_state.as<GenState>();
-    HIPCHK(launch_decode_begin(st, s));
+    HIPCHK(launch_decode_begin(st, m->H / m->KV, s));
     HIPCHK(launch_embed_gather(&st->token, 1, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
     HIPCHK(launch_rmsnorm(m->w_h.as<float>(), 1, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
     const int nl = (int)m->layers.size();

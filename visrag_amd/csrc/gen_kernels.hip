@@ -224,17 +224,17 @@ hipError_t launch_sample(const float* logits, int vocab, unsigned* seen, float p
 // whole cache (len + 1 rows); one query row x 28 heads would be 28 workgroups, so the cache is cut into up to
 // GEN_ATT_SPLITS ranges (multiples of the attention kernel's 64-key tile, ~128 keys or more each) that run as
 // independent "sequences" sharing the query row; ranges past the end are empty (the attention kernel skips them).
-__global__ void decode_begin_kernel(GenState* __restrict__ st) {
+__global__ void decode_begin_kernel(GenState* __restrict__ st, int q_rows) {
     if (threadIdx.x != 0) return;
     const int L = st->len + 1;
     int splits = min(GEN_ATT_SPLITS, max(1, (L + 127) / 128));
     const int chunk = ((L + splits - 1) / splits + 63) / 64 * 64;
     splits = (L + chunk - 1) / chunk;
     st->splits = splits;
-    for (int i = 0; i <= GEN_ATT_SPLITS; ++i) { st->cu_q[i] = i; st->cu_kv[i] = min(L, i * chunk); }
+    for (int i = 0; i <= GEN_ATT_SPLITS; ++i) { st->cu_q[i] = i * q_rows; st->cu_kv[i] = min(L, i * chunk); }
 }
-hipError_t launch_decode_begin(GenState* st, hipStream_t s) {
-    hipLaunchKernelGGL(decode_begin_kernel, dim3(1), dim3(64), 0, s, st);
+hipError_t launch_decode_begin(GenState* st, int q_rows, hipStream_t s) {
+    hipLaunchKernelGGL(decode_begin_kernel, dim3(1), dim3(64), 0, s, st, q_rows);
     return hipGetLastError();
 }
 
@@ -294,17 +294,21 @@ hipError_t launch_patch_rows_u8(const uint8_t* const* pages, const int* page_w, 
     return hipGetLastError();
 }
 
-// one decode step's attention was run as S independent KV ranges (attention_kernel with q_shared): merge them
-__global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, const float* __restrict__ lse, int S, int heads,
+// one decode step's attention was run as S independent KV ranges (attention_kernel with q_shared), the `group` query
+// heads of a KV head as the rows of a tile (layout: kernels.h, SkinnyCombine): merge the ranges.  (The decode step itself
+// merges inside its o projection — gemm_skinny.hip, COMBINE; this kernel serves K ranges longer than that kernel's ring.)
+__global__ void attn_combine_kernel(const bf16_t* __restrict__ part, const float* __restrict__ lse, int S, int heads, int group,
                                     bf16_t* __restrict__ out, const int* __restrict__ S_dev) {
     if (S_dev) S = *S_dev;
     const int h = blockIdx.x, d = threadIdx.x;        // 128 threads: one per channel of the head
+    const int kvh = heads / group, hkv = h / group, g = h % group;
     // every load up front (S <= GEN_ATT_SPLITS): the sums below then run without waiting on memory
     float l[GEN_ATT_SPLITS], pv[GEN_ATT_SPLITS];
 #pragma unroll
     for (int s = 0; s < GEN_ATT_SPLITS; ++s) {
-        l[s] = s < S ? lse[s * heads + h] : -INFINITY;
-        pv[s] = s < S ? bf2f(part[(size_t)s * ldp + h * 128 + d]) : 0.f;
+        const int r = (min(s, max(S - 1, 0)) * group + g) * kvh + hkv;
+        l[s] = s < S ? lse[r] : -INFINITY;
+        pv[s] = bf2f(part[(size_t)r * 128 + d]);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -312,15 +316,16 @@ __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, int ldp, co
     float num = 0.f, den = 0.f;
 #pragma unroll
     for (int s = 0; s < GEN_ATT_SPLITS; ++s) {
-        const float w = s < S ? exp2f(l[s] - mx) : 0.f;
+        const float w = exp2f(l[s] - mx);
         num += w * pv[s];
         den += w;
     }
     out[h * 128 + d] = f2bf(num / den);
 }
-hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s,
+hipError_t launch_attn_combine(const void* part, const float* lse, int S, int heads, int group, void* out, hipStream_t s,
                                const int* S_dev) {
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(heads), dim3(128), 0, s, (const bf16_t*)part, ldp, lse, S, heads, (bf16_t*)out, S_dev);
+    if (group <= 0 || heads % group) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(heads), dim3(128), 0, s, (const bf16_t*)part, lse, S, heads, group, (bf16_t*)out, S_dev);
     return hipGetLastError();
 }
 

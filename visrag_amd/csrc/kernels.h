@@ -42,7 +42,12 @@ hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
 
 // M <= 16 rows (gemm_skinny.hip): the decode step's weight streamer; fp32 planes out[split][M][ldo] (+ bias with split 0)
 // swiglu (ksplit 1, 16-row [gate | up] interleaved W): out = bf16 act [M][ldo] = silu(gate) * up instead of a plane
-hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu = false);
+// combine (M = 1, K = heads * 128): the A row is merged on the fly from the decode step's partial attention rows
+// (bf16 part[S][ldp], lse f32 [S][heads]: see launch_attn_combine) — no separate merge launch
+// part / lse come from the decode attention with the `group` query heads of a KV head as ROWS: range t, query head hq =
+// hkv * group + g  ->  part[((t * group + g) * (heads / group) + hkv) * 128 + d],  lse[(t * group + g) * (heads / group) + hkv]
+struct SkinnyCombine { const void* part; const float* lse; int S; int heads; int group; const int* S_dev; };
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu = false, const struct SkinnyCombine* combine = nullptr);
 // act = silu(gate) * up from the fp32 planes of a gate/up GEMM over 16-row interleaved weights
 hipError_t launch_swiglu_sum(const float* parts, int n_parts, size_t plane_stride, int ldp, int M, int I, void* act, int lda,
                              hipStream_t s);
@@ -71,6 +76,8 @@ struct AttnArgs {
     int causal, q_shared;            // q_shared: q rows [0,max_q) are the same for every batch item
     float scale;
     int kv_group;                    // grouped-query attention: query head h reads K/V head h / kv_group (0 or 1: one each)
+    int q_head_stride;               // elements between the heads of a q row (0: head_dim) — lets the query HEADS of a
+                                     // grouped-query group be handed in as the ROWS of one tile (decode: K/V read once per group)
     float* lse;                      // optional f32 [rows_q][heads]: log2 of the row's softmax denominator (with the running
                                      // max folded in) — lets a caller merge attention over separately processed KV ranges
 };
@@ -89,7 +96,7 @@ struct GenState {
     int pad;
     int cu_q[GEN_ATT_SPLITS + 1], cu_kv[GEN_ATT_SPLITS + 1];
 };
-hipError_t launch_decode_begin(GenState* st, hipStream_t s);
+hipError_t launch_decode_begin(GenState* st, int q_rows, hipStream_t s);   // q_rows: query rows per KV range (the GQA group size)
 // multimodal RoPE on q (in place into q_out) and k (into the K cache at rows cache_row0 + t), v copied into the V
 // cache; head_dim 128; pos3 = [3][pos_stride] ints (temporal, height, width); inv_freq f32 [64]; source = bf16 qkv rows
 // or (parts != null) fp32 split-K planes + bias; cu_kv (optional) receives {0, cache_row0 + T}
@@ -116,8 +123,8 @@ hipError_t launch_patch_rows_u8(const uint8_t* const* pages, const int* page_w, 
                                 int P, int tp, const float* mean3, const float* std3, void* dst, int ld, hipStream_t s);
 // out[h*128 + d] = sum_s 2^(lse[s][h] - max) * part[s][h*128 + d] / sum_s 2^(lse[s][h] - max): merges the S partial
 // attention rows (bf16 [S][ldp], each normalised over its own KV range) of one decode step
-hipError_t launch_attn_combine(const void* part, int ldp, const float* lse, int S, int heads, void* out, hipStream_t s,
-                               const int* S_dev = nullptr);      // S_dev: S read on the device
+hipError_t launch_attn_combine(const void* part, const float* lse, int S, int heads, int group, void* out, hipStream_t s,
+                               const int* S_dev = nullptr);      // S_dev: S read on the device; layout: see SkinnyCombine
 
 // ---- elementwise / gather / pooling (misc.hip) ---------------------------------------------
 // Fused ToTensor/Normalize + patch-embed conv (patch_embed.hip): g carries the PERMUTED weight (k = ky*3P + kx*3 + c),

@@ -235,7 +235,8 @@ def iter_synth_gen_weights(cfg: "GenConfig", seed: int = 0, device="cpu", bf16: 
         yield k, (t.to(torch.bfloat16) if bf16 else t)
 
 
-def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2, device: int = 0, vision: bool = True) -> dict:
+def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2, device: int = 0, vision: bool = True,
+                   chain=None) -> dict:
     """EVisRAG-7B-shaped generation (BASELINE config 5: the top retrieved pages go to the generator, one query at a
     time like src/evisrag/predict.py:128-149): random weights of Qwen2.5-VL-7B (vision tower + language model), pages
     as the image processor's pixel rows (448 x 448: 32 x 32 patches -> 16 x 16 image tokens).  Returns vision / prefill
@@ -314,6 +315,20 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
     torch.cuda.synchronize(device); b = time.perf_counter()
     llm._continue(tok, int(pos3.max()) + 1, answer_tokens, sp, (), False)
     torch.cuda.synchronize(device); host_dec = (time.perf_counter() - b) / max(1, answer_tokens - 1)
+    # pages as u8 images, image processing on the GPU (what generate() does with PIL pages): tower + prefill again
+    pages_ms = None
+    if vision:
+        pg = [torch.from_numpy(rng.integers(0, 256, size=(448, 448, 3), dtype=np.uint8)).to(f"cuda:{device}") for _ in range(n_images)]
+        short = [int(t) for t in rng.integers(1000, 50000, 60)] + [cfg.image_token_id, 198] * n_images + [int(t) for t in rng.integers(1000, 50000, 60)]
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(device); a = time.perf_counter()
+            dev_pages, thw2 = process_pages_gpu(pg, vc, device)
+            llm.prefill_images(short, dev_pages, thw2)
+            llm.sample(sp, 0)
+            torch.cuda.synchronize(device); ts.append(time.perf_counter() - a)
+        pages_ms = float(np.median(ts)) * 1e3
+    e2e = chain(llm) if chain is not None else None        # bench.py: query encode -> search -> page fetch -> generate
     llm.close()
     T, p_s, d_s = len(ids), float(np.median(pre)), float(np.median(dec))
     return {
@@ -323,6 +338,7 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
         "params_billion": round(params / 1e9, 3), "load_s": round(t_load, 1),
         "vision_ms": round(vis_ms, 2) if vision else None, "vision_tflops": round(vis_tf, 1) if vision else None,
         "prefill_ms": round(p_s * 1e3, 2), "prefill_includes_vision": bool(vision),
+        "prefill_ms_from_u8_pages": round(pages_ms, 2) if pages_ms is not None else None, "end_to_end": e2e,
         "prefill_tokens_per_s": round(T / p_s), "prefill_tflops": round(2.0 * stream * T / (p_s - (vis_ms or 0.0) * 1e-3) / 1e12, 1),
         "decode_ms_per_token": round(d_s * 1e3, 3), "decode_tokens_per_s": round(1.0 / d_s, 1),
         "decode_ms_per_token_host_driven": round(host_dec * 1e3, 3),
