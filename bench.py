@@ -166,6 +166,12 @@ def main():
 
     # ---- retrieval: fill the shard to index_rows/world rows with synthetic unit-norm embeddings,
     #      encode the text queries with the model, then time sharded search
+    # the timed steps walked the pool of 2 x batch distinct pages several times: keep ONE embedding of each page in the
+    # retrieval index (copies of a page are exact ties — a property of this loop, not of a corpus)
+    index.reset()
+    for it, px in batches:
+        enc.encode_items(it, device_slices=px, out=out)
+        index.add(out)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     have = len(index)
     filler = torch.randn((rows_local - min(have, rows_local), cfg.hidden_size), generator=g, device=dev)

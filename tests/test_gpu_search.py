@@ -436,3 +436,26 @@ def test_sharded_search_over_rccl(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+@pytest.mark.parametrize("nq", [1, 40])
+def test_wide_band_is_rescored_inside_the_merge(nq):
+    """100 near-duplicates at the top (more than the 64 sorted candidates, fewer than the merge's 256-entry buffer): every
+    row inside the error band is re-scored in the merge kernel — exact ids without the pass over the whole index; four
+    exact copies of a page tie and come out lowest id first."""
+    dim, nd, k, n_dup = 2304, 20000, 10, 100
+    C = _unit(nd, dim, 61)
+    Q = _unit(nq, dim, 62)
+    rng = np.random.default_rng(63)
+    base = Q[0] + 0.5 * _unit(1, dim, 64)[0]
+    base /= np.linalg.norm(base)
+    cluster = 3000 + 11 * np.arange(n_dup)
+    C[cluster] = base[None, :] + 1e-4 * rng.standard_normal((n_dup, dim)).astype(np.float32)
+    C[cluster] /= np.linalg.norm(C[cluster], axis=1, keepdims=True)
+    C[[17000, 17001, 17002]] = C[cluster[0]]                                  # exact copies
+    ix = HipIndex(dim, nd); ix.add(C)
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    assert st["exact_pass"] == 0 and st["regathered"] >= 1, st

@@ -196,7 +196,7 @@ template <int KP>
 __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
     constexpr int GD = KP + MERGE_GD_EXTRA < 64 ? KP + MERGE_GD_EXTRA : 64;
     __shared__ uint64_t lm[256];
-    __shared__ uint64_t surv[MERGE_CAP];
+    __shared__ uint64_t surv[MERGE_CAP], exact_w[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];
     __shared__ uint64_t thr_s;
     __shared__ unsigned drop_s;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
     float dropB = drop_s ? orderable_f32(drop_s) : -INFINITY;
     if (p.thr_used) dropB = fmaxf(dropB, p.thr_used[q]);
     certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
-                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); });
+                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); }, surv, exact_w);
 }
 
 int search_kprime(int k) {

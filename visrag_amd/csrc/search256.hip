@@ -255,7 +255,7 @@ template <int KP>
 __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     constexpr int GD = KP + MERGE_GD_EXTRA < 64 ? KP + MERGE_GD_EXTRA : 64;   // gather depth: certification may want candidates past the KP-th
     __shared__ uint64_t lm[256];
-    __shared__ uint64_t surv[MERGE_CAP];
+    __shared__ uint64_t surv[MERGE_CAP], exact_w[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];
     __shared__ uint64_t thr_s;
     __shared__ int n_s, x_s, comp_s;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     float dropB = p.thr_used ? p.thr_used[q] : -INFINITY;
     if (comp_s && cand[KP - 1] != KEY_NONE) dropB = fmaxf(dropB, key_score(cand[KP - 1]));
     certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
-                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); });
+                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); }, surv, exact_w);
 }
 
 template <int KP>

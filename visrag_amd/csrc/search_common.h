@@ -124,9 +124,13 @@ __device__ __forceinline__ void emit_slot(const SearchArgs& p, int q, int slot, 
 // are complete down to tau (dropB < tau), so that only a query with more than 64 rows inside the error band —
 // or incomplete lists — pays for the exact pass.
 // Called by all 256 threads of the query's workgroup; cand / coverB / dropB must be visible (barrier).
+// surv / exact_w: LDS[MERGE_CAP] — what regather() gathered (unsorted) and scratch for its exact keys: when more than 64
+// rows lie inside the error band (a cluster of near-duplicate pages) but no more than MERGE_CAP, ALL of them are re-scored
+// here and the top k taken from that — the exact pass over the whole index is for what exceeds even this.
 template <int KP, typename Regather>
 __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
-                                             float coverB, float dropB, float* sh_tau, int* sh_x, Regather regather) {
+                                             float coverB, float dropB, float* sh_tau, int* sh_x, Regather regather,
+                                             const uint64_t* surv, uint64_t* exact_w) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = p.dim >> 2;
     const float* qrow = p.q_f32 + (size_t)q * p.dim;
@@ -165,6 +169,26 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
     if (again) {                                         // workgroup-uniform
         if (tid == 0 && p.stats) atomicAdd(&p.stats[4], 1u);
         const int n = regather(tau);
+        if (n > 64 && n <= MERGE_CAP && key_score(cand[63]) >= tau) {
+            // the band holds more than the 64 sorted candidates, but all n of its rows sit in surv: re-score every one
+            for (int c = wave; c < n; c += 4) {
+                const uint64_t key = surv[c];
+                const uint32_t id = ~(uint32_t)key;
+                const float a = wave_sum(dot_lane(qv, p.index_f32 + (size_t)id * p.dim, nv, lane));
+                if (lane == 0) exact_w[c] = make_key(a, id);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                uint64_t best = KEY_NONE;
+                for (int base = 0; base < n; base += 64) {
+                    const uint64_t key = base + lane < n ? exact_w[base + lane] : KEY_NONE;
+                    best = base == 0 ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
+                }
+                if (lane < p.k) emit_slot(p, q, lane, best);
+                if (lane == 0 && p.stats) atomicAdd(&p.stats[1], 1u);
+            }
+            return;
+        }
         coverB = n > 64 ? key_score(cand[63]) : -INFINITY;
     }
     if (wave == 0) {

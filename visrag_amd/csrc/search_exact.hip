@@ -43,17 +43,21 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const float* __restri
             qs[b * nv + c] = reinterpret_cast<const f32x4*>(q_f32 + (size_t)flag_list[f0 + b] * dim)[c];
         }
         __syncthreads();
-        for (int64_t blk = blockIdx.x; blk * EX_ROWS < n_docs; blk += gridDim.x)
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = blk * EX_ROWS + wave * 16 + r;
-            if (row >= n_docs) break;                             // wave-uniform
+        // this wave's rows in order: 16 of every row block the workgroup walks; the next row's loads are in flight while
+        // the current row is scored (two register sets, swapped by unrolling the loop twice)
+        auto row_at = [&](int i) -> int64_t {
+            return ((int64_t)blockIdx.x + (int64_t)(i >> 4) * gridDim.x) * EX_ROWS + wave * 16 + (i & 15);
+        };
+        auto load_row = [&](f32x4 (&dv)[MERGE_MAXV], int64_t row) {
+            if (row >= n_docs) return;
             const f32x4* dr = reinterpret_cast<const f32x4*>(index_f32 + (size_t)row * dim);
-            f32x4 dv[MERGE_MAXV];
 #pragma unroll
             for (int i = 0; i < MERGE_MAXV; ++i) {
                 const int c = lane + i * 64;
                 dv[i] = (c < nv) ? dr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        };
+        auto score_row = [&](const f32x4 (&dv)[MERGE_MAXV], int64_t row) {
             for (int b = 0; b < nb; ++b) {
                 float a = 0.f;
 #pragma unroll
@@ -64,6 +68,15 @@ __global__ __launch_bounds__(256) void exact_scores_kernel(const float* __restri
                 a = wave_sum(a);
                 if (lane == 0) S[(size_t)(f0 + b) * ldS + row] = a;
             }
+        };
+        f32x4 dA[MERGE_MAXV], dB[MERGE_MAXV];
+        load_row(dA, row_at(0));
+        for (int i = 0; row_at(i) < n_docs; i += 2) {             // (rows grow with i: wave-uniform exit)
+            load_row(dB, row_at(i + 1));
+            score_row(dA, row_at(i));
+            if (row_at(i + 1) >= n_docs) break;
+            load_row(dA, row_at(i + 2));
+            score_row(dB, row_at(i + 1));
         }
     }
 }
