@@ -954,7 +954,16 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
     const size_t pstride = (size_t)T * E;
     float* part = m->w_part.as<float>();
     bool pend = false;                   // h still lacks residual_scale * sum(partials)
-    auto proj = [&](const void* A, int lda, const Linear& L) -> int {
+#ifndef VR_DEC_O_GLDS
+#define VR_DEC_O_GLDS 0
+#endif
+    auto proj = [&](const void* A, int lda, const Linear& L, bool is_o = false) -> int {
+        if (VR_DEC_O_GLDS && is_o && !m->taps_on) {
+            // A/B knob: the o projection (K = E: the smaller of the two) on 128 x 128 tiles straight into the residual stream
+            GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;
+            HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_GLDS, s));
+            return VR_OK;
+        }
         if (ks > 1) {
             GemmArgs a = gemm_args(A, lda, L, T, part, E);
             a.ksplit = ks; a.split_stride = pstride;
@@ -991,7 +1000,7 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
             a.max_q = max_len; a.causal = 1; a.q_shared = 0; a.scale = 1.0f / sqrtf(64.0f);
             HIPCHK(launch_attention(a, s));
         }
-        VRCHK(proj(m->w_datt.p, E, L.o));
+        VRCHK(proj(m->w_datt.p, E, L.o, true));
         VRCHK(norm(L.ln2.v.as<float>()));
         { GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
         VRCHK(proj(m->w_dact.p, m->Ip, L.down));
