@@ -395,21 +395,14 @@ def process_pages_gpu(images, vc: "VisionConfig", device: int = 0):
     smart_resize's size (Pillow-exact bicubic on the GPU: vr_resize_bicubic; a page already at that size is only
     uploaded) + image_grid_thw.  Rescale / normalise / patchify happen inside vg_vision_encode_pages."""
     import torch
-    from .gpu_resize import resize_bicubic
+    from .gpu_resize import resize_bicubic, to_device_u8
     p, m = vc.patch_size, vc.spatial_merge_size
     pages, grids = [], []
     for im in images:
-        if isinstance(im, torch.Tensor):
-            a = im
-            h, w = int(a.shape[0]), int(a.shape[1])
-        else:
-            a = np.ascontiguousarray(np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8))
-            h, w = a.shape[:2]
+        a = to_device_u8(im, device)                       # pinned staging + asynchronous upload
+        h, w = int(a.shape[0]), int(a.shape[1])
         H, W = smart_resize(h, w, p * m, vc.min_pixels, vc.max_pixels)
-        if (H, W) == (h, w):
-            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(a).to(f"cuda:{device}")
-        else:
-            t = resize_bicubic(a, (W, H), device)
+        t = a if (H, W) == (h, w) else resize_bicubic(a, (W, H), device)
         pages.append(t.contiguous())
         grids.append((1, H // p, W // p))
     return pages, np.asarray(grids, dtype=np.int32)

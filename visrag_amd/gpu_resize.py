@@ -35,17 +35,63 @@ def resize_bicubic(img, size: Tuple[int, int], device: int = 0) -> torch.Tensor:
     return out
 
 
+class PageUploader:
+    """One pinned staging buffer + one device buffer per user (a pipeline slot): the u8 pixels of a whole batch of pages
+    cross the bus in ONE asynchronous copy on the current stream; the pages come back as views of the device buffer.
+    (Per-page uploads cost a pageable-memory copy and a stream synchronisation each — with batches in flight that wait is
+    the previous batch's encode; `tensor.pin_memory()` per page is slower still: 1.6 ms per page measured.)"""
+
+    def __init__(self, device: int = 0):
+        self.device = int(device)
+        self._pin: Optional[torch.Tensor] = None
+        self._ev: Optional[torch.cuda.Event] = None
+
+    def upload(self, images) -> List[Optional[torch.Tensor]]:
+        arrs = [None if im is None else (im if isinstance(im, torch.Tensor) else
+                                         np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8)) for im in images]
+        host = [a for a in arrs if a is not None and not isinstance(a, torch.Tensor)]
+        total = sum(int(a.size) for a in host)
+        if total == 0:
+            return arrs
+        if self._ev is not None:
+            self._ev.synchronize()                         # the previous upload has left the staging buffer (long ago)
+        if self._pin is None or self._pin.numel() < total:
+            self._pin = torch.empty(max(total, 1 << 24), dtype=torch.uint8, pin_memory=True)
+        pin_np = self._pin.numpy()
+        off, spans = 0, []
+        for a in arrs:
+            if a is None or isinstance(a, torch.Tensor):
+                spans.append(None)
+                continue
+            n = int(a.size)
+            pin_np[off:off + n] = a.reshape(-1)
+            spans.append((off, n, a.shape))
+            off += n
+        dev = torch.empty(total, dtype=torch.uint8, device=f"cuda:{self.device}")
+        dev.copy_(self._pin[:total], non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record(torch.cuda.current_stream(self.device))
+        return [a if sp is None else dev[sp[0]:sp[0] + sp[1]].view(sp[2]) for a, sp in zip(arrs, spans)]
+
+
+def to_device_u8(img, device: int = 0) -> torch.Tensor:
+    """PIL image / u8 HWC array -> cuda uint8 tensor (a cuda tensor passes through)."""
+    if isinstance(img, torch.Tensor):
+        return img
+    a = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img, dtype=np.uint8)
+    return torch.from_numpy(np.array(a, copy=True)).to(f"cuda:{device}")
+
+
 def slice_image_gpu(img, cfg, device: int = 0):
     """-> (list of cuda uint8 HWC slices [source, patches row-major...], best_grid|None)."""
-    if isinstance(img, torch.Tensor):
-        H, W = int(img.shape[0]), int(img.shape[1])
-    else:
-        img = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img, dtype=np.uint8)
-        H, W = img.shape[:2]
+    img = to_device_u8(img, device)
+    H, W = int(img.shape[0]), int(img.shape[1])
     size = (W, H)
     grid = choose_grid(size, cfg.max_slice_nums, cfg.scale_resolution)
     if grid is None:
         best = find_best_resize(size, cfg.scale_resolution, cfg.patch_size, allow_upscale=True)
+        if tuple(best) == size:
+            return [img.contiguous()], None               # already at its encode size: the upload is the slice
         return [resize_bicubic(img, best, device)], None
     src = resize_bicubic(img, find_best_resize(size, cfg.scale_resolution, cfg.patch_size), device)
     refine = get_refine_size(size, grid, cfg.scale_resolution, cfg.patch_size, allow_upscale=True)
@@ -71,8 +117,7 @@ def prepare_item_gpu(text: str, image, tokenizer, cfg, max_inp_length: Optional[
         if grid is not None:
             ph += get_grid_placeholder(tokenizer, grid, cfg.query_num)
     else:   # slice_mode=False: the image as it is, one plain placeholder (modeling_visrag_ret.py:70-72)
-        a = np.asarray(image.convert("RGB") if hasattr(image, "convert") else image, dtype=np.uint8)
-        dev_slices = [torch.from_numpy(np.ascontiguousarray(a)).to(f"cuda:{device}")]
+        dev_slices = [to_device_u8(image, device).contiguous()]
     it = prepare_item(ph + "\n" + text, None, tokenizer, cfg, max_inp_length)
     it.slices = list(dev_slices)        # device tensors: HipEncoder.encode_items passes them on as they are
     return it, dev_slices

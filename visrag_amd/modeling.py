@@ -55,6 +55,7 @@ class DRModelForInference:
         # while batch i is still on the GPU; the caller's stream waits for each result, never the reverse.
         self._slots = [(encoder, None)]
         self._rr = 0
+        self._uploaders = {}            # per slot: pinned staging + device buffer for a batch's page pixels
         # page resize + slicing on the GPU (bit-identical to PIL, gpu_resize.py) instead of on the host
         self.gpu_preprocess = gpu_preprocess
 
@@ -128,9 +129,11 @@ class DRModelForInference:
 
         def run():
             if self.gpu_preprocess and any(im is not None for im in images):
-                from .gpu_resize import prepare_item_gpu
+                from .gpu_resize import PageUploader, prepare_item_gpu
+                up = self._uploaders.setdefault(id(enc), PageUploader(enc.device))
+                dev_images = up.upload(images)             # the whole batch's pixels in one asynchronous copy
                 prepared = [prepare_item_gpu(t, im, tokenizer, self.cfg, max_inp_length, enc.device)[0]
-                            for t, im in zip(texts, images)]
+                            for t, im in zip(texts, dev_images)]
             else:
                 prepared = prepare_batch(texts, images, tokenizer, self.cfg, max_inp_length)
             return self.encode_prepared(prepared, enc)
