@@ -36,6 +36,8 @@ typedef struct {
     float rms_norm_eps;             /* 1e-6 */
     float rope_theta;               /* 1e6 */
     int32_t mrope_section[3];       /* rotary channel pairs that take the temporal / height / width position: 16, 24, 24 */
+    int32_t max_seqs;               /* sequences the model can hold at once (KV cache, logits, seen-token set per slot);
+                                     * 0 or 1 = one sequence, at most 16 (vg_select / vg_decode_batch) */
 } vg_config_t;
 
 int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out);
@@ -119,6 +121,19 @@ int vg_run_begin(vg_model_t m, int32_t position, float temperature, float repeti
 int vg_run_step(vg_model_t m);
 int vg_run_token(vg_model_t m, int32_t index, int32_t* token);
 int vg_run_end(vg_model_t m);
+/* Several sequences in one model (max_seqs slots, each with its own KV cache, logits and seen-token set) — what
+ * vLLM does with the list `llm.generate` is given (predict.py:147 passes one prompt at a time; a caller that has several
+ * queries pending can pass them together).  vg_select makes `slot` the sequence that vg_prefill / vg_vision_encode +
+ * vg_prefill / vg_sample / vg_decode / vg_run_* / vg_logits / vg_cache_len work on (slot 0 after vg_create).
+ * vg_decode_batch appends ONE token to each of n distinct slots (every one with a sequence in progress) as a single
+ * step: every weight matrix is streamed once for the n rows (the decode step is bound by that stream), attention runs
+ * per sequence over its own cache.  pos = [n][3] positions.  vg_sample_batch samples the next token of each of the n
+ * slots from its logits with the rules of vg_sample.  Rows are computed independently of each other: a sequence's
+ * tokens do not depend on what it is batched with. */
+int vg_select(vg_model_t m, int32_t slot);
+int vg_decode_batch(vg_model_t m, int32_t n, const int32_t* slots, const int32_t* tokens, const int32_t* pos, void* stream);
+int vg_sample_batch(vg_model_t m, int32_t n, const int32_t* slots, float temperature, float repetition_penalty, uint64_t seed,
+                    int32_t step, int32_t* tokens_out, void* stream);
 /* copy the current logits (f32 [vocab]) to the host — tests */
 int vg_logits(vg_model_t m, float* out, void* stream);
 int vg_cache_len(vg_model_t m, int32_t* len);

@@ -197,3 +197,47 @@ def test_run_api_errors(setup):
     t0 = llm.run_token(0)
     assert 0 <= t0 < cfg.vocab_size
     llm.run_end()
+
+
+def test_batched_generation_equals_one_at_a_time():
+    """llm.generate with several prompts on a model that holds several sequences (max_num_seqs, vLLM's name): one
+    vg_decode_batch step per token serves all of them — and every prompt gets exactly the tokens it gets alone (rows of
+    a step are independent), for prompts of different lengths incl. one with an image block, a sequence that stops early,
+    greedy and with temperature; more prompts than slots run in groups."""
+    from visrag_amd.evisrag import LLM, SamplingParams
+    g = np.load(GOLD)
+    cfg = tiny_config()
+    w = synth_weights(cfg, seed=int(g["seed"]))
+    rng = np.random.default_rng(3)
+    prompts = [{"prompt_token_ids": g["a_ids"].tolist()},
+               {"prompt_token_ids": g["b_ids"].tolist(), "multi_modal_data": {"image_embeds": [g["b_image_embeds"]], "image_grids": [(6, 4)]}},
+               {"prompt_token_ids": rng.integers(6, cfg.vocab_size, 150).tolist()},
+               {"prompt_token_ids": rng.integers(6, cfg.vocab_size, 3).tolist()},
+               {"prompt_token_ids": rng.integers(6, cfg.vocab_size, 77).tolist()}]
+    one = LLM(_gen_cfg(cfg), max_model_len=512, max_prefill=256, weights=w)
+    many = LLM(_gen_cfg(cfg), max_model_len=512, max_prefill=256, weights=w, max_num_seqs=3)
+    try:
+        for temperature in (0.0, 0.8):
+            sp = SamplingParams(temperature=temperature, repetition_penalty=1.05, max_tokens=40, seed=5, stop_token_ids=())
+            ref = [one.generate([p], sp)[0].outputs[0].token_ids for p in prompts]
+            got = many.generate(prompts, sp)
+            assert [o.outputs[0].token_ids for o in got] == ref, temperature
+            assert [o.prompt_token_ids for o in got] == [p["prompt_token_ids"] for p in prompts]
+            # a stop token ends one sequence early; the others run on
+            stop = ref[2][7]
+            sp2 = SamplingParams(temperature=temperature, repetition_penalty=1.05, max_tokens=40, seed=5, stop_token_ids=(stop,))
+            ref2 = [one.generate([p], sp2)[0].outputs[0].token_ids for p in prompts[:3]]
+            got2 = [o.outputs[0].token_ids for o in many.generate(prompts[:3], sp2)]
+            assert got2 == ref2 and len(got2[2]) <= 8
+        # the single-sequence entry points still work on a multi-slot model, on any slot
+        many.select(2)
+        many.prefill(g["a_ids"].tolist())
+        one.prefill(g["a_ids"].tolist())
+        np.testing.assert_array_equal(many.logits(), one.logits())
+        many.select(0)
+        with pytest.raises(Exception):
+            many.select(3)
+        with pytest.raises(Exception):
+            many.decode_batch([0, 0], [7, 8], [5, 5])                     # a slot named twice
+    finally:
+        one.close(); many.close()

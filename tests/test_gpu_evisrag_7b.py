@@ -165,3 +165,24 @@ def test_tower_at_7b_shape_on_a_5k_row_page(setup):
     assert np.abs(emb - ref).max() < 2e-2 * scale, (np.abs(emb - ref).max(), scale)
     cos = (emb * ref).sum(-1) / (np.linalg.norm(emb, axis=-1) * np.linalg.norm(ref, axis=-1))
     assert cos.min() > 1 - 1e-3, cos.min()
+
+
+def test_batched_decode_at_7b_shape(setup):
+    """Five prompts (the five-page one and four text prompts of different lengths) decoded together on a five-slot model
+    of the same weights: 12 tokens each, identical to one-at-a-time generation (M = 5 rows through the skinny GEMMs'
+    7B K splits, per-sequence KV ranges at a 1405-row and at short caches in one attention launch)."""
+    from visrag_amd.evisrag import LLM, SamplingParams
+    cfg, vcfg, host, wv, llm, ids, embs = setup
+    w = {k: v.cuda() for k, v in host.items()}
+    many = LLM(_gen_cfg(cfg), max_model_len=2048, max_prefill=1536, weights=w, max_num_seqs=5)
+    del w
+    try:
+        rng = np.random.default_rng(9)
+        prompts = [{"prompt_token_ids": ids, "multi_modal_data": {"image_embeds": embs, "image_grids": [GRID] * N_IMG}}] + \
+                  [{"prompt_token_ids": rng.integers(16, cfg.vocab_size, n).tolist()} for n in (40, 300, 129, 700)]
+        sp = SamplingParams(temperature=0.0, repetition_penalty=1.05, max_tokens=12, stop_token_ids=())
+        ref = [llm.generate([p], sp)[0].outputs[0].token_ids for p in prompts]
+        got = [o.outputs[0].token_ids for o in many.generate(prompts, sp)]
+        assert got == ref
+    finally:
+        many.close()

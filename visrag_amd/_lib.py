@@ -32,7 +32,7 @@ class VGConfig(C.Structure):       # vg_config_t (include/visrag_gen.h)
     _fields_ = [
         ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
         ("intermediate_size", C.c_int32), ("vocab_size", C.c_int32), ("max_len", C.c_int32), ("max_prefill", C.c_int32),
-        ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float), ("mrope_section", C.c_int32 * 3),
+        ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float), ("mrope_section", C.c_int32 * 3), ("max_seqs", C.c_int32),
     ]
 
 
@@ -99,6 +99,9 @@ GEN_SIGNATURES = {
     "vg_sample": (C.c_int, [_vp, _f32, _f32, C.c_uint64, _i32, C.POINTER(_i32), _vp]),
     "vg_decode": (C.c_int, [_vp, _i32, C.POINTER(_i32), _vp]),
     "vg_logits": (C.c_int, [_vp, _vp, _vp]),
+    "vg_select": (C.c_int, [_vp, _i32]),
+    "vg_decode_batch": (C.c_int, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "vg_sample_batch": (C.c_int, [_vp, _i32, C.POINTER(_i32), _f32, _f32, C.c_uint64, _i32, C.POINTER(_i32), _vp]),
     "vg_cache_len": (C.c_int, [_vp, C.POINTER(_i32)]),
     "vg_run_begin": (C.c_int, [_vp, _i32, _f32, _f32, C.c_uint64, _i32, _vp]),
     "vg_run_step": (C.c_int, [_vp]),

@@ -114,13 +114,14 @@ __global__ __launch_bounds__(256, QF >= 4 ? 1 : (PIPE == 3 ? 3 : 2)) void attent
     const int qt = t % q_tiles, bh = t / q_tiles;
     const int h = bh % p.heads, b = bh / p.heads;
 
-    const int kv0 = p.cu_kv[b], kv_len = p.cu_kv[b + 1] - kv0;
+    const int kv0 = p.cu_kv[b], kv_len = (p.kv_end ? p.kv_end[b] : p.cu_kv[b + 1]) - kv0;
     const int q_row0 = p.cu_q[b];                      // rows of `out` (and of q unless shared)
     const int q_len = p.cu_q[b + 1] - q_row0;
     const int qs = qt * QT;                            // first query of this tile (seq-relative)
     if (qs >= q_len || kv_len <= 0) return;
 
-    const bf16_t* qbase = (const bf16_t*)p.q + (size_t)(p.q_shared ? 0 : q_row0) * p.ldq + h * (p.q_head_stride ? p.q_head_stride : HD);
+    const bf16_t* qbase = (const bf16_t*)p.q + (size_t)(p.q_in_rows ? p.q_in_rows[b] : (p.q_shared ? 0 : q_row0)) * p.ldq +
+                          h * (p.q_head_stride ? p.q_head_stride : HD);
     const int hkv = p.kv_group > 1 ? h / p.kv_group : h;          // grouped-query attention: K/V head of this query head
     const bf16_t* kbase = (const bf16_t*)p.k + (size_t)kv0 * p.ldk + hkv * HD;
     const bf16_t* vbase = (const bf16_t*)p.v + (size_t)kv0 * p.ldv + hkv * HD;

@@ -61,6 +61,7 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
     if (c.hidden_size > 3584) return fail(VR_ERR_INVALID, "hidden_size %d is beyond this build's row kernels (<= 3584: Qwen2.5-VL-3B / 7B)", c.hidden_size);
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return fail(VR_ERR_INVALID, "mrope sections must add up to 64 channel pairs");
     if (c.num_layers <= 0 || c.max_len <= 0 || c.max_prefill <= 0 || c.max_prefill > c.max_len) return fail(VR_ERR_INVALID, "bad layer / length settings");
+    if (c.max_seqs < 0 || c.max_seqs > 16) return fail(VR_ERR_INVALID, "max_seqs %d: 0 / 1 (one sequence) up to 16", c.max_seqs);
     VRCHK(set_dev(device_id));
     vg_model_s* m = new vg_model_s();
     m->device = device_id;
@@ -70,6 +71,9 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
     m->layers.resize(c.num_layers);
     m->kc.resize(c.num_layers);
     m->vc.resize(c.num_layers);
+    m->n_slots = std::max(1, c.max_seqs);
+    m->slot_len.assign(m->n_slots, 0);
+    m->slot_logits.assign(m->n_slots, 0);
     *out = m;
     auto bail = [&](int rc) { vg_destroy(m); *out = nullptr; return rc; };
     // rotary frequencies exactly as the reference builds them: 1 / theta^(2p / 128) in fp32 (modeling_qwen2_5_vl.py:519-523)
@@ -79,8 +83,8 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
     if ((rc = m->inv_freq.alloc(64 * 4)) != VR_OK) return bail(rc);
     if (hipMemcpy(m->inv_freq.p, inv.data(), 64 * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(VR_ERR_HIP, "hipMemcpy failed"));
     for (int l = 0; l < c.num_layers; ++l) {
-        if ((rc = m->kc[l].alloc((size_t)c.max_len * m->KVD * 2)) != VR_OK) return bail(rc);
-        if ((rc = m->vc[l].alloc((size_t)c.max_len * m->KVD * 2)) != VR_OK) return bail(rc);
+        if ((rc = m->kc[l].alloc((size_t)m->n_slots * c.max_len * m->KVD * 2)) != VR_OK) return bail(rc);
+        if ((rc = m->vc[l].alloc((size_t)m->n_slots * c.max_len * m->KVD * 2)) != VR_OK) return bail(rc);
     }
     const size_t T = (size_t)pad256(c.max_prefill);
     m->Tcap = (int)T;
@@ -88,11 +92,11 @@ extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out)
     struct { DevBuf* b; size_t bytes; } ws[] = {
         {&m->w_h, T * E * 4}, {&m->w_xn, T * E * 2}, {&m->w_qkv, T * m->QKV * 2}, {&m->w_q, T * m->QD * 2},
         {&m->w_att, T * m->QD * 2}, {&m->w_act, T * (size_t)pad128(m->I) * 2}, {&m->w_last, 256 * E * 2},
-        {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(std::max<size_t>(m->QKV, E), (size_t)pad128(2 * m->I)) * 4}, {&m->w_logits, (size_t)m->V * 4},
+        {&m->w_part, (size_t)GEN_KS_MAX * std::max<size_t>(std::max<size_t>(m->QKV, E), (size_t)pad128(2 * m->I)) * 4}, {&m->w_logits, (size_t)m->n_slots * m->V * 4},
         {&m->w_ids, T * 4}, {&m->w_pos, 3 * T * 4}, {&m->w_cu, 4 * 4},
-        {&m->w_attp, (size_t)GEN_ATT_SPLITS * m->QD * 2}, {&m->w_lse, (size_t)GEN_ATT_SPLITS * m->H * 4}, {&m->w_seen, (size_t)(m->V + 31) / 32 * 4},
+        {&m->w_attp, (size_t)m->n_slots * GEN_ATT_SPLITS * m->QD * 2}, {&m->w_lse, (size_t)m->n_slots * GEN_ATT_SPLITS * m->H * 4}, {&m->w_seen, (size_t)m->n_slots * ((m->V + 31) / 32) * 4},
         {&m->w_tok, 16 + 64 * 8}, {&m->w_erows, T * 4}, {&m->w_emb, T * E * 4},
-        {&m->w_state, sizeof(GenState)}};
+        {&m->w_state, sizeof(GenState)}, {&m->w_batch, sizeof(GenBatch)}, {&m->w_logits_b, (size_t)(m->n_slots > 1 ? m->n_slots : 0) * m->V * 4}};
     for (auto& w : ws)
         if ((rc = w.b->alloc(w.bytes)) != VR_OK) return bail(rc);
     return VR_OK;
@@ -210,13 +214,13 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
         GenState* st = m->w_state.as<GenState>();          // position and cache row of the step: on the device
         HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV * T, L.qkv.b.as<float>(), QKV, T, m->H, m->KV, st->pos,
                                   1, c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD,
-                                  m->kc[l].p, m->vc[l].p, m->KVD, 0, nullptr, s, &st->len));
+                                  gen_kc(m, l, m->cur), gen_vc(m, l, m->cur), m->KVD, 0, nullptr, s, &st->len));
     } else {
         GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, T, m->w_qkv.p, QKV);
         HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s));
         HIPCHK(launch_mrope_cache(m->w_qkv.p, nullptr, 0, 0, nullptr, QKV, T, m->H, m->KV, m->w_pos.as<int>(), m->Tcap,
-                                  c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD, m->kc[l].p,
-                                  m->vc[l].p, m->KVD, m->len, nullptr, s));
+                                  c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD, gen_kc(m, l, m->cur),
+                                  gen_vc(m, l, m->cur), m->KVD, m->len, nullptr, s));
     }
     // ---- grouped-query attention over the cache.  Prefill: causal within the prompt.  Decode: the new row sees the
     //      whole cache; one query row x 28 heads would be 28 workgroups, so the cache is cut into KV ranges
@@ -225,7 +229,7 @@ static int gen_layer(vg_model_s* m, int l, int T, bool decode, const float* next
     //      GenState::splits real ones by their log-sum-exps.  Nothing here depends on a host-side length.
     {
         AttnArgs a{};
-        a.q = m->w_q.p; a.ldq = QD; a.k = m->kc[l].p; a.ldk = m->KVD; a.v = m->vc[l].p; a.ldv = m->KVD;
+        a.q = m->w_q.p; a.ldq = QD; a.k = gen_kc(m, l, m->cur); a.ldk = m->KVD; a.v = gen_vc(m, l, m->cur); a.ldv = m->KVD;
         a.heads = m->H; a.head_dim = 128; a.scale = 1.0f / sqrtf(128.0f); a.kv_group = m->H / m->KV;
         if (decode) {
             // the G = H / KV query heads that share a KV head are the ROWS of one tile (q_head_stride): a KV range is read
@@ -302,7 +306,7 @@ static int gen_head(vg_model_s* m, const float* h_row, bool normed, hipStream_t 
         HIPCHK(launch_rmsnorm(h_row, 1, E, E, m->final_norm.v.as<float>(), m->c.rms_norm_eps, m->w_last.p, E, s));
         A = m->w_last.p;
     }
-    GemmArgs a = gen_gemm_args(A, E, m->lm_head, 1, m->w_logits.p, m->lm_head.n_pad);
+    GemmArgs a = gen_gemm_args(A, E, m->lm_head, 1, gen_logits(m, m->cur), m->lm_head.n_pad);
     HIPCHK(launch_gemm_skinny(a, s));
     m->have_logits = true;
     return VR_OK;
@@ -327,13 +331,13 @@ extern "C" int vg_prefill(vg_model_t m, const int32_t* ids, int32_t T, const int
     m->len = 0;
     m->have_logits = false;
     m->tok_on_device = false;
-    HIPCHK(hipMemsetAsync(m->w_seen.p, 0, m->w_seen.bytes, s));
+    HIPCHK(hipMemsetAsync(gen_seen(m, m->cur), 0, (size_t)((m->V + 31) / 32) * 4, s));
     HIPCHK(hipMemcpyAsync(m->w_ids.p, ids, (size_t)T * 4, hipMemcpyHostToDevice, s));
     for (int c = 0; c < 3; ++c)
         HIPCHK(hipMemcpyAsync(m->w_pos.as<int>() + (size_t)c * m->Tcap, pos3 + (size_t)c * T, (size_t)T * 4, hipMemcpyHostToDevice, s));
     const int cu_host[4] = {0, T, 0, T};              // cu_q, cu_kv
     HIPCHK(hipMemcpyAsync(m->w_cu.p, cu_host, sizeof(cu_host), hipMemcpyHostToDevice, s));
-    HIPCHK(launch_mark_seen(m->w_ids.as<int>(), T, m->w_seen.as<unsigned>(), m->V, s));
+    HIPCHK(launch_mark_seen(m->w_ids.as<int>(), T, gen_seen(m, m->cur), m->V, s));
     HIPCHK(launch_embed_gather(m->w_ids.as<int>(), T, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
     if (n_embed > 0) {
         HIPCHK(hipMemcpyAsync(m->w_erows.p, embed_rows, (size_t)n_embed * 4, hipMemcpyHostToDevice, s));
@@ -366,7 +370,7 @@ static int enqueue_decode(vg_model_s* m, hipStream_t s, bool sampled, float temp
         VRCHK(gen_layer(m, l, 1, true, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : m->final_norm.v.as<float>(), s));
     VRCHK(gen_head(m, nullptr, true, s));
     if (sampled)
-        HIPCHK(launch_sample(m->w_logits.as<float>(), m->V, m->w_seen.as<unsigned>(), penalty, temperature, seed, 0, m->w_tok.as<int>(),
+        HIPCHK(launch_sample(gen_logits(m, m->cur), m->V, gen_seen(m, m->cur), penalty, temperature, seed, 0, m->w_tok.as<int>(),
                              m->w_tok.as<unsigned long long>() + 2, s, st, 1, 1));
     return VR_OK;
 }
@@ -403,7 +407,7 @@ extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penal
     VRCHK(set_dev(m->device));
     VRCHK(end_run(m));
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(launch_sample(m->w_logits.as<float>(), m->V, m->w_seen.as<unsigned>(), repetition_penalty, temperature, seed,
+    HIPCHK(launch_sample(gen_logits(m, m->cur), m->V, gen_seen(m, m->cur), repetition_penalty, temperature, seed,
                          (unsigned)step, m->w_tok.as<int>(), m->w_tok.as<unsigned long long>() + 2, s, m->w_state.as<GenState>(), 0, 0));
     HIPCHK(hipMemcpyAsync(token_out, m->w_tok.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -413,6 +417,7 @@ extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penal
 
 // ---- free-running generation ------------------------------------------------------------------------------------
 static int capture_step(vg_model_s* m, float temperature, float penalty, unsigned long long seed) {
+    // (vg_select drops the graph when the slot changes: it bakes the slot's cache / logits / seen pointers in)
     if (m->graph_exec && m->g_temp == temperature && m->g_pen == penalty && m->g_seed == seed) return VR_OK;
     drop_graph(m);
     HIPCHK(hipStreamBeginCapture(m->run_stream, hipStreamCaptureModeRelaxed));
@@ -482,12 +487,170 @@ extern "C" int vg_run_end(vg_model_t m) {
     return end_run(m);
 }
 
+// ---- several sequences ---------------------------------------------------------------------------------------------
+extern "C" int vg_select(vg_model_t m, int32_t slot) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    if (slot < 0 || slot >= m->n_slots) return fail(VR_ERR_INVALID, "slot %d: the model holds %d sequence(s) (vg_config_t::max_seqs)", slot, m->n_slots);
+    VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
+    if (slot == m->cur) return VR_OK;
+    m->slot_len[m->cur] = m->len; m->slot_logits[m->cur] = m->have_logits;
+    m->cur = slot;
+    m->len = m->slot_len[slot]; m->have_logits = m->slot_logits[slot] != 0;
+    m->tok_on_device = false;
+    drop_graph(m);
+    return VR_OK;
+}
+
+// one decoder layer of a batched decode step: n rows, one per sequence, each with its own cache rows
+static int gen_layer_batch(vg_model_s* m, int l, int n, const float* next_norm, hipStream_t s) {
+    const vg_config_t& c = m->c;
+    GenLayer& L = m->layers[l];
+    const int E = m->E, QD = m->QD, QKV = m->QKV, Ip = pad128(m->I), G = m->H / m->KV;
+    float* h = m->w_h.as<float>();
+    float* part = m->w_part.as<float>();
+    GenBatch* bt = m->w_batch.as<GenBatch>();
+    {   // q | k | v: one pass over the weights for the n rows, then rotate + append to each sequence's cache
+        GemmArgs a = gen_gemm_args(m->w_xn.p, E, L.qkv, n, part, QKV);
+        a.bias = nullptr;
+        a.ksplit = choose_ksplit(QKV, E, VR_KS_QKV);
+        a.split_stride = (size_t)QKV * n;
+        HIPCHK(launch_gemm_skinny(a, s));
+        HIPCHK(launch_mrope_cache(nullptr, part, a.ksplit, (size_t)QKV * n, L.qkv.b.as<float>(), QKV, n, m->H, m->KV, &bt->pos[0][0], 16,
+                                  c.mrope_section[0], c.mrope_section[1], m->inv_freq.as<float>(), m->w_q.p, QD, m->kc[l].p, m->vc[l].p,
+                                  m->KVD, 0, nullptr, s, nullptr, bt->cache_row));
+    }
+    {   // attention: item (r, range) = the group's query heads of row r against one KV range of ITS cache
+        AttnArgs a{};
+        a.q = m->w_q.p; a.ldq = 128; a.q_head_stride = G * 128; a.q_in_rows = bt->q_in;
+        a.k = m->kc[l].p; a.ldk = m->KVD; a.v = m->vc[l].p; a.ldv = m->KVD;
+        a.cu_q = bt->cu_q; a.cu_kv = bt->kv_lo; a.kv_end = bt->kv_hi;
+        a.heads = m->KV; a.kv_group = 1; a.head_dim = 128; a.scale = 1.0f / sqrtf(128.0f);
+        a.out = m->w_attp.p; a.ldo = m->KVD; a.B = n * GEN_ATT_SPLITS; a.max_q = G; a.causal = 0; a.q_shared = 0;
+        a.lse = m->w_lse.as<float>();
+        HIPCHK(launch_attention(a, s));
+        HIPCHK(launch_attn_combine(m->w_attp.p, m->w_lse.as<float>(), 0, m->H, G, m->w_att.p, s, bt->splits, n, QD));
+    }
+    {
+        GemmArgs a = gen_gemm_args(m->w_att.p, QD, L.o, n, part, E);
+        a.ksplit = choose_ksplit(E, QD, VR_KS_O);
+        a.split_stride = (size_t)E * n;
+        HIPCHK(launch_gemm_skinny(a, s));
+        HIPCHK(launch_rmsnorm_accum(h, n, E, E, part, a.ksplit, (size_t)E * n, E, 1.0f, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_xn.p, E, s));
+    }
+    {
+        const int N2 = L.gu.n_pad;
+        GemmArgs g = gen_gemm_args(m->w_xn.p, E, L.gu, n, part, N2);
+        g.ksplit = choose_ksplit(N2, E, VR_KS_GU);
+        if (g.ksplit == 1) {
+            g.out = m->w_act.p; g.ldo = Ip;
+            HIPCHK(launch_gemm_skinny(g, s, true));
+        } else {
+            g.split_stride = (size_t)N2 * n;
+            HIPCHK(launch_gemm_skinny(g, s));
+            HIPCHK(launch_swiglu_sum(part, g.ksplit, (size_t)N2 * n, N2, n, m->I, m->w_act.p, Ip, s));
+        }
+        GemmArgs a = gen_gemm_args(m->w_act.p, Ip, L.down, n, part, E);
+        a.ksplit = choose_ksplit(E, L.down.k_pad, VR_KS_DOWN);
+        a.split_stride = (size_t)E * n;
+        HIPCHK(launch_gemm_skinny(a, s));
+        HIPCHK(launch_rmsnorm_accum(h, n, E, E, part, a.ksplit, (size_t)E * n, E, 1.0f, next_norm, c.rms_norm_eps, m->w_xn.p, E, s));
+    }
+    return VR_OK;
+}
+
+extern "C" int vg_decode_batch(vg_model_t m, int32_t n, const int32_t* slots, const int32_t* tokens, const int32_t* pos, void* stream) {
+    if (!m || !slots || !tokens || !pos) return fail(VR_ERR_INVALID, "NULL argument");
+    if (!m->finalized) return fail(VR_ERR_STATE, "vg_finalize has not succeeded");
+    if (n <= 0 || n > m->n_slots || n > 16) return fail(VR_ERR_INVALID, "%d rows: the model holds %d sequence(s), a step takes at most 16", n, m->n_slots);
+    VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
+    m->slot_len[m->cur] = m->len; m->slot_logits[m->cur] = m->have_logits;
+    const int G = m->H / m->KV;
+    {   // the widest split-K plane set of the step must fit the partial buffer
+        const size_t cap = m->w_part.bytes / 4;
+        const size_t need = (size_t)n * std::max({(size_t)choose_ksplit(m->QKV, m->E, VR_KS_QKV) * m->QKV, (size_t)choose_ksplit(m->E, m->QD, VR_KS_O) * m->E,
+                                                  (size_t)choose_ksplit(m->E, pad128(m->I), VR_KS_DOWN) * m->E});
+        if (need > cap) return fail(VR_ERR_CAPACITY, "%d rows need %zu partial-sum floats (%zu available)", n, need, cap);
+    }
+    GenBatch b{};
+    unsigned used = 0;
+    for (int r = 0; r < n; ++r) {
+        const int sl = slots[r];
+        if (sl < 0 || sl >= m->n_slots || (used >> sl) & 1u) return fail(VR_ERR_INVALID, "row %d: slot %d is out of range or named twice", r, sl);
+        used |= 1u << sl;
+        const int len = m->slot_len[sl];
+        if (len <= 0) return fail(VR_ERR_STATE, "slot %d has no sequence in progress (vg_select + vg_prefill first)", sl);
+        if (len >= m->c.max_len) return fail(VR_ERR_CAPACITY, "slot %d: KV cache is full (%d rows)", sl, m->c.max_len);
+        if (tokens[r] < 0 || tokens[r] >= m->V) return fail(VR_ERR_INVALID, "token id %d out of range", tokens[r]);
+        b.token[r] = tokens[r];
+        for (int c = 0; c < 3; ++c) b.pos[c][r] = pos[3 * r + c];
+        const int base = sl * m->c.max_len;
+        b.cache_row[r] = base + len;
+        // KV ranges of the row's attention: decode_begin_kernel's split of its L = len + 1 cache rows
+        const int L = len + 1;
+        int splits = std::min(GEN_ATT_SPLITS, std::max(1, (L + 127) / 128));
+        const int chunk = ((L + splits - 1) / splits + 63) / 64 * 64;
+        splits = (L + chunk - 1) / chunk;
+        b.splits[r] = splits;
+        for (int t = 0; t < GEN_ATT_SPLITS; ++t) {
+            const int it = r * GEN_ATT_SPLITS + t;
+            b.kv_lo[it] = base + std::min(L, t * chunk);
+            b.kv_hi[it] = base + std::min(L, (t + 1) * chunk);
+            b.q_in[it] = r * m->H;                       // q rows are 128 wide: row r's heads start at r * H
+        }
+    }
+    for (int it = 0; it <= n * GEN_ATT_SPLITS; ++it) b.cu_q[it] = it * G;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(m->w_batch.p, &b, sizeof(b), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                     // `b` lives on this frame
+    GenBatch* bt = m->w_batch.as<GenBatch>();
+    const int E = m->E;
+    HIPCHK(launch_embed_gather(bt->token, n, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
+    HIPCHK(launch_rmsnorm(m->w_h.as<float>(), n, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
+    const int nl = (int)m->layers.size();
+    for (int l = 0; l < nl; ++l)
+        VRCHK(gen_layer_batch(m, l, n, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : m->final_norm.v.as<float>(), s));
+    {   // lm_head over the n normed rows, then every row to its slot's logits
+        GemmArgs a = gen_gemm_args(m->w_xn.p, E, m->lm_head, n, m->w_logits_b.p, m->lm_head.n_pad);
+        HIPCHK(launch_gemm_skinny(a, s));
+        for (int r = 0; r < n; ++r)
+            HIPCHK(hipMemcpyAsync(gen_logits(m, slots[r]), m->w_logits_b.as<float>() + (size_t)r * m->lm_head.n_pad, (size_t)m->V * 4,
+                                  hipMemcpyDeviceToDevice, s));
+    }
+    for (int r = 0; r < n; ++r) { m->slot_len[slots[r]] += 1; m->slot_logits[slots[r]] = 1; }
+    m->len = m->slot_len[m->cur]; m->have_logits = m->slot_logits[m->cur] != 0;
+    m->tok_on_device = false;
+    return VR_OK;
+}
+
+extern "C" int vg_sample_batch(vg_model_t m, int32_t n, const int32_t* slots, float temperature, float repetition_penalty, uint64_t seed,
+                               int32_t step, int32_t* tokens_out, void* stream) {
+    if (!m || !slots || !tokens_out) return fail(VR_ERR_INVALID, "NULL argument");
+    if (n <= 0 || n > m->n_slots || n > 16) return fail(VR_ERR_INVALID, "%d rows: the model holds %d sequence(s)", n, m->n_slots);
+    if (!(repetition_penalty > 0.f) || temperature < 0.f) return fail(VR_ERR_INVALID, "bad sampling parameters");
+    VRCHK(set_dev(m->device));
+    VRCHK(end_run(m));
+    m->slot_logits[m->cur] = m->have_logits;
+    for (int r = 0; r < n; ++r)
+        if (slots[r] < 0 || slots[r] >= m->n_slots || !m->slot_logits[slots[r]]) return fail(VR_ERR_STATE, "slot %d has no logits", slots[r]);
+    hipStream_t s = (hipStream_t)stream;
+    int* toks = m->w_batch.as<GenBatch>()->sampled;
+    for (int r = 0; r < n; ++r)
+        HIPCHK(launch_sample(gen_logits(m, slots[r]), m->V, gen_seen(m, slots[r]), repetition_penalty, temperature, seed, (unsigned)step,
+                             toks + r, m->w_tok.as<unsigned long long>() + 2, s, nullptr, 0, 0));
+    HIPCHK(hipMemcpyAsync(tokens_out, toks, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    m->tok_on_device = false;
+    return VR_OK;
+}
+
 extern "C" int vg_logits(vg_model_t m, float* out, void* stream) {
     if (!m || !out) return fail(VR_ERR_INVALID, "NULL argument");
     if (!m->have_logits) return fail(VR_ERR_STATE, "no logits yet");
     VRCHK(set_dev(m->device));
     VRCHK(end_run(m));
-    HIPCHK(hipMemcpyAsync(out, m->w_logits.p, (size_t)m->V * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(out, gen_logits(m, m->cur), (size_t)m->V * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VR_OK;
 }

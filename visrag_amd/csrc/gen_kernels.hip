@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restri
                                                           int pos_stride, int sec_t, int sec_h, const float* __restrict__ inv_freq,
                                                           bf16_t* __restrict__ q_out, int ldq, bf16_t* __restrict__ k_cache,
                                                           bf16_t* __restrict__ v_cache, int ld_cache, int cache_row0,
-                                                          int* __restrict__ cu_kv, const int* __restrict__ row0_dev) {
+                                                          int* __restrict__ cu_kv, const int* __restrict__ row0_dev,
+                                                          const int* __restrict__ cache_rows) {
     if (row0_dev) cache_row0 = *row0_dev;              // decode steps: the cache length lives on the device (GenState::len)
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -71,10 +72,11 @@ __global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restri
         const float r1 = x1 * cs - x2 * sn, r2 = x2 * cs + x1 * sn;                      // x*cos + rotate_half(x)*sin
         x1 = r1; x2 = r2;
     }
+    const size_t crow = cache_rows ? (size_t)cache_rows[t] : (size_t)(cache_row0 + t);   // (batched decode: one cache per row)
     bf16_t* dst;
     if (hs < H) dst = q_out + (size_t)t * ldq + col;
-    else if (hs < H + KV) dst = k_cache + (size_t)(cache_row0 + t) * ld_cache + (hs - H) * 128;
-    else dst = v_cache + (size_t)(cache_row0 + t) * ld_cache + (hs - H - KV) * 128;
+    else if (hs < H + KV) dst = k_cache + crow * ld_cache + (hs - H) * 128;
+    else dst = v_cache + crow * ld_cache + (hs - H - KV) * 128;
     dst[lane] = f2bf(x1);
     dst[64 + lane] = f2bf(x2);
 }
@@ -82,12 +84,12 @@ __global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restri
 hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_parts, size_t plane_stride, const float* bias,
                               int ld, int T, int H, int KV, const int* pos3, int pos_stride, int sec_t, int sec_h,
                               const float* inv_freq, void* q_out, int ldq, void* k_cache, void* v_cache, int ld_cache,
-                              int cache_row0, int* cu_kv, hipStream_t s, const int* row0_dev) {
+                              int cache_row0, int* cu_kv, hipStream_t s, const int* row0_dev, const int* cache_rows) {
     if (T <= 0) return hipSuccess;
     const int slots = T * (H + 2 * KV);
     hipLaunchKernelGGL(mrope_cache_kernel, dim3((slots + 3) / 4), dim3(256), 0, s, (const bf16_t*)src_bf16, parts, n_parts,
                        plane_stride, bias, ld, T, H, KV, pos3, pos_stride, sec_t, sec_h, inv_freq, (bf16_t*)q_out, ldq,
-                       (bf16_t*)k_cache, (bf16_t*)v_cache, ld_cache, cache_row0, cu_kv, row0_dev);
+                       (bf16_t*)k_cache, (bf16_t*)v_cache, ld_cache, cache_row0, cu_kv, row0_dev, cache_rows);
     return hipGetLastError();
 }
 
@@ -298,10 +300,14 @@ hipError_t launch_patch_rows_u8(const uint8_t* const* pages, const int* page_w, 
 // heads of a KV head as the rows of a tile (layout: kernels.h, SkinnyCombine): merge the ranges.  (The decode step itself
 // merges inside its o projection — gemm_skinny.hip, COMBINE; this kernel serves K ranges longer than that kernel's ring.)
 __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, const float* __restrict__ lse, int S, int heads, int group,
-                                    bf16_t* __restrict__ out, const int* __restrict__ S_dev) {
-    if (S_dev) S = *S_dev;
+                                    bf16_t* __restrict__ out, const int* __restrict__ S_dev, int ld_out) {
+    const int row = blockIdx.y;                       // batched decode: sequence `row` of the step
+    if (S_dev) S = S_dev[row];
     const int h = blockIdx.x, d = threadIdx.x;        // 128 threads: one per channel of the head
     const int kvh = heads / group, hkv = h / group, g = h % group;
+    part += (size_t)row * GEN_ATT_SPLITS * heads * 128;
+    lse += (size_t)row * GEN_ATT_SPLITS * heads;
+    out += (size_t)row * ld_out;
     // every load up front (S <= GEN_ATT_SPLITS): the sums below then run without waiting on memory
     float l[GEN_ATT_SPLITS], pv[GEN_ATT_SPLITS];
 #pragma unroll
@@ -323,9 +329,10 @@ __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, const float
     out[h * 128 + d] = f2bf(num / den);
 }
 hipError_t launch_attn_combine(const void* part, const float* lse, int S, int heads, int group, void* out, hipStream_t s,
-                               const int* S_dev) {
-    if (group <= 0 || heads % group) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(heads), dim3(128), 0, s, (const bf16_t*)part, lse, S, heads, group, (bf16_t*)out, S_dev);
+                               const int* S_dev, int n_rows, int ld_out) {
+    if (group <= 0 || heads % group || n_rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(heads, n_rows), dim3(128), 0, s, (const bf16_t*)part, lse, S, heads, group,
+                       (bf16_t*)out, S_dev, ld_out);
     return hipGetLastError();
 }
 

@@ -28,9 +28,13 @@ struct vg_model_s {
     Vec final_norm;
     Linear lm_head;
     DevBuf inv_freq;
-    std::vector<DevBuf> kc, vc;          // per layer [max_len][KVD] bf16
-    int len = 0;                         // rows of the cache in use
-    bool have_logits = false;
+    std::vector<DevBuf> kc, vc;          // per layer [n_slots * max_len][KVD] bf16: slot s owns rows [s * max_len, (s + 1) * max_len)
+    int n_slots = 1, cur = 0;            // sequences the model holds; the one the single-sequence entry points work on
+    std::vector<int> slot_len;           // cache rows in use per slot (the current slot's lives in `len`)
+    std::vector<char> slot_logits;       // per slot: logits are on the device
+    int len = 0;                         // rows of the CURRENT slot's cache in use
+    bool have_logits = false;            // the current slot has logits on the device
+    DevBuf w_batch, w_logits_b;          // vg_decode_batch: the step's device-side tables; logits rows of the batch
     int Tcap = 0;
     DevBuf w_h, w_xn, w_qkv, w_q, w_att, w_act, w_last, w_part, w_logits, w_ids, w_pos, w_cu, w_seen, w_tok, w_erows, w_emb;
     DevBuf w_attp, w_lse;               // decode: partial attention rows [GEN_ATT_SPLITS][QD] bf16 + their log-sum-exps
@@ -50,6 +54,12 @@ struct vg_model_s {
     VisionTower* vis = nullptr;         // attached by vg_vision_create
     int vis_tokens = 0;                 // embedding rows the last vg_vision_encode left in w_emb (image-token order)
 };
+
+// per-slot views of the sequence state
+static inline void* gen_kc(vg_model_s* m, int l, int slot) { return (char*)m->kc[l].p + (size_t)slot * m->c.max_len * m->KVD * 2; }
+static inline void* gen_vc(vg_model_s* m, int l, int slot) { return (char*)m->vc[l].p + (size_t)slot * m->c.max_len * m->KVD * 2; }
+static inline float* gen_logits(vg_model_s* m, int slot) { return m->w_logits.as<float>() + (size_t)slot * m->V; }
+static inline unsigned* gen_seen(vg_model_s* m, int slot) { return m->w_seen.as<unsigned>() + (size_t)slot * ((m->V + 31) / 32); }
 
 static inline GemmArgs gen_gemm_args(const void* A, int lda, const Linear& L, int M, void* out, int ldo) {
     GemmArgs a{};

@@ -76,6 +76,9 @@ struct AttnArgs {
     int causal, q_shared;            // q_shared: q rows [0,max_q) are the same for every batch item
     float scale;
     int kv_group;                    // grouped-query attention: query head h reads K/V head h / kv_group (0 or 1: one each)
+    const int* kv_end;               // optional [B]: item b's K/V rows are [cu_kv[b], kv_end[b]) instead of [cu_kv[b], cu_kv[b+1])
+                                     // (ranges of DIFFERENT caches: batched decode)
+    const int* q_in_rows;            // optional [B]: first q row of item b (overrides cu_q / q_shared for READING q; out rows stay cu_q)
     int q_head_stride;               // elements between the heads of a q row (0: head_dim) — lets the query HEADS of a
                                      // grouped-query group be handed in as the ROWS of one tile (decode: K/V read once per group)
     float* lse;                      // optional f32 [rows_q][heads]: log2 of the row's softmax denominator (with the running
@@ -96,6 +99,17 @@ struct GenState {
     int pad;
     int cu_q[GEN_ATT_SPLITS + 1], cu_kv[GEN_ATT_SPLITS + 1];
 };
+// one vg_decode_batch step (up to 16 sequences): built on the host, uploaded once per step
+struct GenBatch {
+    int token[16];
+    int pos[3][16];                                  // [component][row]
+    int cache_row[16];                               // cache row the row's new token goes to: slot * max_len + len
+    int splits[16];                                  // KV ranges of the row's attention
+    int cu_q[16 * GEN_ATT_SPLITS + 1];               // output rows of item (row, range): (row * SPLITS + range) * group
+    int kv_lo[16 * GEN_ATT_SPLITS], kv_hi[16 * GEN_ATT_SPLITS];   // the item's cache rows [lo, hi)
+    int q_in[16 * GEN_ATT_SPLITS];                   // the item's first q row (128-wide rows: row * heads)
+    int sampled[16];                                 // vg_sample_batch: the sampled tokens
+};
 hipError_t launch_decode_begin(GenState* st, int q_rows, hipStream_t s);   // q_rows: query rows per KV range (the GQA group size)
 // multimodal RoPE on q (in place into q_out) and k (into the K cache at rows cache_row0 + t), v copied into the V
 // cache; head_dim 128; pos3 = [3][pos_stride] ints (temporal, height, width); inv_freq f32 [64]; source = bf16 qkv rows
@@ -103,7 +117,8 @@ hipError_t launch_decode_begin(GenState* st, int q_rows, hipStream_t s);   // q_
 hipError_t launch_mrope_cache(const void* src_bf16, const float* parts, int n_parts, size_t plane_stride, const float* bias,
                               int ld, int T, int H, int KV, const int* pos3, int pos_stride, int sec_t, int sec_h,
                               const float* inv_freq, void* q_out, int ldq, void* k_cache, void* v_cache, int ld_cache,
-                              int cache_row0, int* cu_kv, hipStream_t s, const int* row0_dev = nullptr);   // row0_dev: cache_row0 read on the device
+                              int cache_row0, int* cu_kv, hipStream_t s, const int* row0_dev = nullptr,   // row0_dev: cache_row0 read on the device
+                              const int* cache_rows = nullptr);  // cache_rows [T] (device): row t goes to cache row cache_rows[t] (batched decode)
 // vision tower: cs f32 [T][64][2] = (cos, sin)((p < sec_h ? pos_h : pos_w)[t] * freq[p]); then q / k head slots (2 * hh
 // wide, pairs (p, p + hh), hh <= 64) of bf16 qkv rows rotated in place, slots [0, n_slots) at columns slot * 2 * hh
 hipError_t launch_rope2d_table(const int* pos_h, const int* pos_w, int T, int sec_h, const float* freq, void* cs, hipStream_t s);
@@ -124,7 +139,9 @@ hipError_t launch_patch_rows_u8(const uint8_t* const* pages, const int* page_w, 
 // out[h*128 + d] = sum_s 2^(lse[s][h] - max) * part[s][h*128 + d] / sum_s 2^(lse[s][h] - max): merges the S partial
 // attention rows (bf16 [S][ldp], each normalised over its own KV range) of one decode step
 hipError_t launch_attn_combine(const void* part, const float* lse, int S, int heads, int group, void* out, hipStream_t s,
-                               const int* S_dev = nullptr);      // S_dev: S read on the device; layout: see SkinnyCombine
+                               const int* S_dev = nullptr,       // S_dev: S read on the device; layout: see SkinnyCombine
+                               int n_rows = 1, int ld_out = 0);  // batched decode: row r's ranges start at range r * GEN_ATT_SPLITS,
+                                                                 // its count is S_dev[r], its output row is out + r * ld_out
 
 // ---- elementwise / gather / pooling (misc.hip) ---------------------------------------------
 // Fused ToTensor/Normalize + patch-embed conv (patch_embed.hip): g carries the PERMUTED weight (k = ky*3P + kx*3 + c),

@@ -497,7 +497,7 @@ class LLM:
 
     def __init__(self, model, tensor_parallel_size: int = 1, dtype: str = "bfloat16",
                  limit_mm_per_prompt: Optional[Dict[str, int]] = None, max_model_len: Optional[int] = None,
-                 max_prefill: Optional[int] = None,
+                 max_prefill: Optional[int] = None, max_num_seqs: int = 1,
                  device: int = 0, weights=None, detokenize: Optional[Callable[[List[int]], str]] = None,
                  vision: Optional[VisionConfig] = None, max_vision_rows: Optional[int] = None):
         if tensor_parallel_size != 1:
@@ -533,9 +533,12 @@ class LLM:
         self.max_model_len, self.max_prefill = int(max_model_len), int(min(max_prefill, max_model_len))
         self._lib = _lib.load()
         c = self.cfg
+        # max_num_seqs (vLLM's name): sequences decoded together when generate() is handed several prompts — every weight
+        # matrix is streamed once per step for all of them (1 = one at a time, like predict.py's loop; at most 16)
+        self.max_num_seqs = max(1, min(16, int(max_num_seqs)))
         vc = _lib.VGConfig(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, c.intermediate_size,
                            c.vocab_size, self.max_model_len, self.max_prefill, c.rms_norm_eps, c.rope_theta,
-                           (C.c_int32 * 3)(*c.mrope_section))
+                           (C.c_int32 * 3)(*c.mrope_section), self.max_num_seqs)
         h = C.c_void_p()
         _lib.check(self._lib.vg_create(self.device, C.byref(vc), C.byref(h)), "vg_create")
         self._h = h
@@ -686,6 +689,25 @@ class LLM:
                                        C.byref(tok), None), "vg_sample")
         return int(tok.value)
 
+    # ---- several sequences (vg_select / vg_decode_batch / vg_sample_batch) ---------------------------------------------
+    def select(self, slot: int) -> None:
+        _lib.check(self._lib.vg_select(self._h, int(slot)), "vg_select")
+
+    def decode_batch(self, slots: Sequence[int], tokens: Sequence[int], positions: Sequence[int]) -> None:
+        n = len(slots)
+        sl = (C.c_int32 * n)(*[int(x) for x in slots])
+        tk = (C.c_int32 * n)(*[int(x) for x in tokens])
+        ps = (C.c_int32 * (3 * n))(*[int(p) for p in positions for _ in range(3)])
+        _lib.check(self._lib.vg_decode_batch(self._h, n, sl, tk, ps, None), "vg_decode_batch")
+
+    def sample_batch(self, slots: Sequence[int], sp: SamplingParams, step: int) -> List[int]:
+        n = len(slots)
+        sl = (C.c_int32 * n)(*[int(x) for x in slots])
+        out = (C.c_int32 * n)()
+        _lib.check(self._lib.vg_sample_batch(self._h, n, sl, float(sp.temperature), float(sp.repetition_penalty), int(sp.seed),
+                                             int(step), out, None), "vg_sample_batch")
+        return [int(t) for t in out]
+
     def decode(self, token: int, position: int) -> None:
         p = (C.c_int32 * 3)(position, position, position)
         _lib.check(self._lib.vg_decode(self._h, int(token), p, None), "vg_decode")
@@ -747,38 +769,81 @@ class LLM:
     def generate(self, prompts, sampling_params: Optional[SamplingParams] = None, pipelined: bool = True) -> List[RequestOutput]:
         sp = sampling_params or SamplingParams()
         stops = set(sp.stop_token_ids if sp.stop_token_ids is not None else self.cfg.eos_token_ids)
+        if self.max_num_seqs > 1 and len(prompts) > 1:
+            return self._generate_batched(list(prompts), sp, stops)
         outs = []
         for pr in prompts:
-            if pr.get("prompt_token_ids") is not None:
-                ids = list(pr["prompt_token_ids"])
-            elif self.tokenizer is not None:        # predict.py:143: the chat-templated string
-                ids = list(self.tokenizer(pr["prompt"])["input_ids"])
-            else:
-                raise ValueError("a text prompt needs the checkpoint's tokenizer: LLM(model=<checkpoint directory>), or pass prompt_token_ids")
-            mm = pr.get("multi_modal_data") or {}
-            images = mm.get("image")
-            if images is not None and len(images) == 0:
-                images = None                         # a query with no retrieved page: a text-only prompt, like vLLM
-            if images is not None or mm.get("pixel_values") is not None:
-                if self.vision is None:
-                    raise RuntimeError("images need a vision tower: LLM(..., vision=VisionConfig())")
-                # PIL pages: resize on the GPU (Pillow-exact), rescale / normalise / patchify inside the tower call;
-                # processor output handed in by the caller (pixel_values) is used as it is
-                px, grid = (mm["pixel_values"], mm["image_grid_thw"]) if mm.get("pixel_values") is not None \
-                    else (process_pages_gpu(images, self.vision, self.device) if self.gpu_images else process_images(images, self.vision))
-                m2 = self.vision.spatial_merge_size ** 2
-                g = np.asarray(grid).reshape(-1, 3)
-                n_tok = int((g[:, 0] * g[:, 1] * g[:, 2]).sum()) // m2
-                n_ph = sum(1 for t in ids if t == self.cfg.image_token_id)
-                total = len(ids) - n_ph + n_tok if n_ph == len(g) else len(ids)
-                self._check_lengths(total, n_tok * m2)
-                pos3, ids = self.prefill_images(ids, px, grid)
-            else:
-                self._check_lengths(len(ids), 0)
-                pos3 = self.prefill(ids, mm.get("image_embeds", ()), mm.get("image_grids", ()), pr.get("positions"))
+            ids, pos3 = self._prefill_prompt(pr)
             nxt = int(pos3.max()) + 1
             limit = min(sp.max_tokens, self.max_model_len - len(ids))
             toks: List[int] = self._continue(self.sample(sp, 0), nxt, limit, sp, stops, pipelined) if limit > 0 else []
             text = self.detokenize(toks) if self.detokenize else ""
             outs.append(RequestOutput([CompletionOutput(toks, text)], ids))
         return outs
+
+    def _generate_batched(self, prompts, sp: SamplingParams, stops) -> List[RequestOutput]:
+        """Groups of up to max_num_seqs prompts: every prompt is prefilled into its own slot (tower + prefill one after the
+        other, as for a single prompt), then ONE decode step per token serves the whole group (vg_decode_batch: the
+        weights are streamed once for all rows); a sequence that has stopped leaves the group.  Rows are independent: a
+        prompt's tokens are the ones it gets alone (same seed and step index per sequence)."""
+        outs: List[Optional[RequestOutput]] = [None] * len(prompts)
+        for g0 in range(0, len(prompts), self.max_num_seqs):
+            group = prompts[g0:g0 + self.max_num_seqs]
+            ids_l, nxt, toks, limit, live = [], [], [], [], []
+            for slot, pr in enumerate(group):
+                self.select(slot)
+                ids, pos3 = self._prefill_prompt(pr)
+                ids_l.append(ids); nxt.append(int(pos3.max()) + 1)
+                limit.append(min(sp.max_tokens, self.max_model_len - len(ids)))
+                toks.append([self.sample(sp, 0)] if limit[-1] > 0 else [])
+                if limit[-1] > 1 and toks[-1][0] not in stops:
+                    live.append(slot)
+            step = 1
+            while live:
+                self.decode_batch(live, [toks[sl][-1] for sl in live], [nxt[sl] for sl in live])
+                new = self.sample_batch(live, sp, step)
+                still = []
+                for sl, t in zip(live, new):
+                    nxt[sl] += 1
+                    toks[sl].append(t)
+                    if t not in stops and len(toks[sl]) < limit[sl]:
+                        still.append(sl)
+                live = still
+                step += 1
+            self.select(0)
+            for slot in range(len(group)):
+                text = self.detokenize(toks[slot]) if self.detokenize else ""
+                outs[g0 + slot] = RequestOutput([CompletionOutput(toks[slot], text)], ids_l[slot])
+        return outs
+
+    def _prefill_prompt(self, pr) -> Tuple[List[int], np.ndarray]:
+        """One prompt of generate() into the current slot: tokenise if needed, run the tower on its pages, prefill.
+        Returns (prompt ids with the image placeholders expanded, positions)."""
+        if pr.get("prompt_token_ids") is not None:
+            ids = list(pr["prompt_token_ids"])
+        elif self.tokenizer is not None:        # predict.py:143: the chat-templated string
+            ids = list(self.tokenizer(pr["prompt"])["input_ids"])
+        else:
+            raise ValueError("a text prompt needs the checkpoint's tokenizer: LLM(model=<checkpoint directory>), or pass prompt_token_ids")
+        mm = pr.get("multi_modal_data") or {}
+        images = mm.get("image")
+        if images is not None and len(images) == 0:
+            images = None                         # a query with no retrieved page: a text-only prompt, like vLLM
+        if images is not None or mm.get("pixel_values") is not None:
+            if self.vision is None:
+                raise RuntimeError("images need a vision tower: LLM(..., vision=VisionConfig())")
+            # PIL pages: resize on the GPU (Pillow-exact), rescale / normalise / patchify inside the tower call;
+            # processor output handed in by the caller (pixel_values) is used as it is
+            px, grid = (mm["pixel_values"], mm["image_grid_thw"]) if mm.get("pixel_values") is not None \
+                else (process_pages_gpu(images, self.vision, self.device) if self.gpu_images else process_images(images, self.vision))
+            m2 = self.vision.spatial_merge_size ** 2
+            g = np.asarray(grid).reshape(-1, 3)
+            n_tok = int((g[:, 0] * g[:, 1] * g[:, 2]).sum()) // m2
+            n_ph = sum(1 for t in ids if t == self.cfg.image_token_id)
+            total = len(ids) - n_ph + n_tok if n_ph == len(g) else len(ids)
+            self._check_lengths(total, n_tok * m2)
+            pos3, ids = self.prefill_images(ids, px, grid)
+        else:
+            self._check_lengths(len(ids), 0)
+            pos3 = self.prefill(ids, mm.get("image_embeds", ()), mm.get("image_grids", ()), pr.get("positions"))
+        return ids, pos3
