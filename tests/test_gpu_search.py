@@ -282,7 +282,7 @@ def _assert_ids_equal_fp64(ids, sc, C, Q, k):
 
 
 @pytest.mark.parametrize("n_dup,nq,k", [(20, 1, 10), (64, 1, 10), (300, 1, 10), (20, 40, 10), (64, 40, 10), (300, 300, 10),
-                                        (300, 5, 26), (200, 3, 60), (2000, 40, 100)])
+                                        (300, 5, 26), (200, 3, 60), (2000, 40, 100), (2000, 1, 10), (2000, 40, 10)])
 def test_search_near_duplicate_cluster_is_exact(n_dup, nq, k):
     """north_star: IDENTICAL top-k doc ids.  A cluster of near-duplicate pages (within 1e-4 of each other: less
     than the bf16 dot-product error, so the bf16 sweep orders them at random) sits at the top of query 0's
@@ -308,8 +308,12 @@ def test_search_near_duplicate_cluster_is_exact(n_dup, nq, k):
     assert st["certified"] + st["certified_extended"] + st["exact_pass"] == nq and st["uncertified"] == 0, st
     if n_dup == 20 and k == 10:
         assert st["certified_extended"] >= 1 and st["exact_pass"] == 0, st   # 4 more candidates re-scored, no full pass
-    if n_dup >= 300:
+    if n_dup >= 2000:                                                        # beyond what the merge re-scores in place (1024 rows)
         assert st["exact_pass"] >= 1, st
+    elif k <= 26 and nq <= 16:
+        # (with more than 16 queries the sweep starts from pre-pass thresholds; a cluster this dense pulls query 0's
+        # threshold up into its own error band, the lists then cannot prove completeness and the exact pass is right)
+        assert st["exact_pass"] == 0, st
     # the same search with certification off is what rounds 1-2 shipped: tolerance-exact only
     ix.set_search_eps(-1.0)
     sc2, ids2 = ix.search(Q, k)
@@ -440,7 +444,7 @@ def test_sharded_search_over_rccl(tmp_path):
 
 @pytest.mark.parametrize("nq", [1, 40])
 def test_wide_band_is_rescored_inside_the_merge(nq):
-    """100 near-duplicates at the top (more than the 64 sorted candidates, fewer than the merge's 256-entry buffer): every
+    """100 near-duplicates at the top (more than the 64 sorted candidates, fewer than the merge's 1024-entry buffer): every
     row inside the error band is re-scored in the merge kernel — exact ids without the pass over the whole index; four
     exact copies of a page tie and come out lowest id first."""
     dim, nd, k, n_dup = 2304, 20000, 10, 100

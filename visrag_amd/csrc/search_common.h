@@ -47,7 +47,7 @@ __device__ __forceinline__ uint64_t wave_merge_top64(uint64_t cur, uint64_t fres
 }
 
 constexpr int MERGE_MAXV = 10;     // dim <= 64 * 4 * MERGE_MAXV
-constexpr int MERGE_CAP = 256;     // survivor buffer per query (merge kernels)
+constexpr int MERGE_CAP = 1024;    // survivor buffer per query (merge kernels): what the certification can re-score in place
 #ifndef VR_MERGE_GD
 #define VR_MERGE_GD 16
 #endif
