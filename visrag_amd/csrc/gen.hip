@@ -50,6 +50,76 @@ static int choose_ksplit(int n, int k, int forced = 0) {
     return best;
 }
 
+// The persistent layer kernel of the decode step (gen_persist.hip): decide whether this model / device takes it and build
+// its layer table for the CURRENT slot (the caches are per slot).  It is OPT-IN — VR_DECODE_PERSIST=1 in the environment
+// when the model is finalized / a slot is selected (or -DVR_DECODE_PERSIST=1) — because on MI355X it only draws level with
+// the separate launches (3.33 against 3.29 ms per token at the 7B shape: its weight streams run at 6.5 TB/s instead of
+// 5.4-5.7, but seven grid barriers per layer cost 4.3 us each under the prefetch traffic).
+#ifndef VR_DECODE_PERSIST
+#define VR_DECODE_PERSIST 0
+#endif
+static int persist_setup(vg_model_s* m) {
+    m->p_grid = 0;
+    const char* env = getenv("VR_DECODE_PERSIST");
+    if (env ? atoi(env) == 0 : !VR_DECODE_PERSIST) return VR_OK;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m->device) != hipSuccess || decode_persist_occupancy() < 1) return VR_OK;
+    const int grid = prop.multiProcessorCount;
+    const int E = m->E, QD = m->QD, QKV = m->QKV, G = m->H / m->KV;
+    const GenLayer& L0 = m->layers[0];
+    const int ks_qkv = choose_ksplit(QKV, E, VR_KS_QKV), ks_o = choose_ksplit(E, QD, VR_KS_O);
+    const int ks_d = choose_ksplit(E, L0.down.k_pad, VR_KS_DOWN), ks_gu = choose_ksplit(L0.gu.n_pad, E, VR_KS_GU);
+    auto per64 = [](int k, int ks) { return ((k / 64 + ks - 1) / ks) * 64; };
+    const bool fits =
+        E <= 4096 && (E / 4 + 63) / 64 <= 16 && (E / 4 + 63) / 64 <= grid && G <= 16 && GEN_ATT_SPLITS * m->KV <= grid && ks_gu == 1 &&
+        L0.qkv.n_pad == QKV && L0.qkv.k_pad == E && L0.o.n_pad == E && L0.o.k_pad == QD && L0.gu.k_pad == E && L0.down.n_pad == E &&
+        L0.down.k_pad == pad128(m->I) && !L0.o.has_b && !L0.gu.has_b && !L0.down.has_b &&
+        (QKV + 255) / 256 * ks_qkv <= grid && (E + 255) / 256 * ks_o <= grid && (E + 255) / 256 * ks_d <= grid && (L0.gu.n_pad + 255) / 256 <= grid &&
+        per64(E, ks_qkv) <= 4096 && per64(QD, ks_o) <= 4096 && per64(L0.down.k_pad, ks_d) <= 4096 &&
+        (size_t)std::max(ks_qkv, std::max(ks_o, ks_d)) * std::max(QKV, E) * 4 <= m->w_part.bytes;
+    if (!fits) return VR_OK;
+    std::vector<PersistLayer> t(m->layers.size());
+    for (size_t l = 0; l < t.size(); ++l) {
+        GenLayer& L = m->layers[l];
+        t[l] = PersistLayer{L.qkv.w.p, L.o.w.p, L.gu.w.p, L.down.w.p, L.qkv.has_b ? L.qkv.b.as<float>() : nullptr,
+                            L.ln1.v.as<float>(), L.ln2.v.as<float>(), gen_kc(m, (int)l, m->cur), gen_vc(m, (int)l, m->cur)};
+    }
+    if (!m->p_table.p) {
+        VRCHK(m->p_table.alloc(t.size() * sizeof(PersistLayer)));
+        VRCHK(m->p_sync.alloc(128 * 8));
+        VRCHK(m->p_ss.alloc(16 * 4));
+        HIPCHK(hipMemset(m->p_sync.p, 0, 128 * 8));
+        HIPCHK(hipMemset(m->p_ss.p, 0, 16 * 4));
+        HIPCHK(hipHostMalloc((void**)&m->p_abort, 64, hipHostMallocMapped));
+        *m->p_abort = 0;
+    }
+    HIPCHK(hipMemcpy(m->p_table.p, t.data(), t.size() * sizeof(PersistLayer), hipMemcpyHostToDevice));
+    m->p_grid = grid;
+    return VR_OK;
+}
+static int persist_layers(vg_model_s* m, hipStream_t s) {
+    const GenLayer& L0 = m->layers[0];
+    PersistArgs a{};
+    a.layers = m->p_table.as<PersistLayer>(); a.n_layers = (int)m->layers.size();
+    a.E = m->E; a.QKV = m->QKV; a.QD = m->QD; a.KVD = m->KVD; a.H = m->H; a.KV = m->KV; a.Ip = L0.down.k_pad; a.N2 = L0.gu.n_pad;
+    a.ldw_qkv = L0.qkv.k_pad; a.ldw_o = L0.o.k_pad; a.ldw_gu = L0.gu.k_pad; a.ldw_d = L0.down.k_pad;
+    a.ks_qkv = choose_ksplit(m->QKV, m->E, VR_KS_QKV); a.ks_o = choose_ksplit(m->E, m->QD, VR_KS_O);
+    a.ks_d = choose_ksplit(m->E, L0.down.k_pad, VR_KS_DOWN);
+    a.eps = m->c.rms_norm_eps; a.g_final = m->final_norm.v.as<float>();
+    a.h = m->w_h.as<float>(); a.xn = m->w_xn.p; a.planes = m->w_part.as<float>(); a.act = m->w_act.p;
+    a.attp = m->w_attp.p; a.lse = m->w_lse.as<float>(); a.ss = m->p_ss.as<float>();
+    a.st = m->w_state.as<GenState>(); a.inv_freq = m->inv_freq.as<float>();
+    a.sec_t = m->c.mrope_section[0]; a.sec_h = m->c.mrope_section[1];
+    a.sync = m->p_sync.as<unsigned long long>(); a.abort_host = m->p_abort;
+    HIPCHK(launch_decode_persist(a, m->p_grid, s));
+    return VR_OK;
+}
+// a barrier of the persistent kernel timed out (the workgroups were not all resident): everything after it is garbage
+static int persist_check(vg_model_s* m) {
+    if (m->p_abort && *m->p_abort) return fail(VR_ERR_HIP, "the decode kernel's grid barrier timed out (its workgroups must all be resident: one per CU)");
+    return VR_OK;
+}
+
 extern "C" int vg_create(int device_id, const vg_config_t* cfg, vg_model_t* out) {
     if (!cfg || !out) return fail(VR_ERR_INVALID, "cfg/out is NULL");
     const vg_config_t& c = *cfg;
@@ -110,7 +180,7 @@ extern "C" int vg_destroy(vg_model_t m) {
     for (auto& e : m->run_ev)
         if (e) (void)hipEventDestroy(e);
     if (m->h_tokens) (void)hipHostFree(m->h_tokens);
-    if (m->run_stream) (void)hipStreamDestroy(m->run_stream);
+    if (m->p_abort) (void)hipHostFree(m->p_abort);
     vision_destroy(m);
     delete m;                           // DevBuf destructors release everything
     return VR_OK;
@@ -192,6 +262,8 @@ extern "C" int vg_finalize(vg_model_t m) {
             return fail(VR_ERR_STATE, "layer %zu is incomplete", i);
     }
     if (m->vis) VRCHK(vision_check_complete(m));
+    VRCHK(set_dev(m->device));
+    VRCHK(persist_setup(m));
     m->finalized = true;
     return VR_OK;
 }
@@ -366,8 +438,12 @@ static int enqueue_decode(vg_model_s* m, hipStream_t s, bool sampled, float temp
     HIPCHK(launch_embed_gather(&st->token, 1, m->embed.p, E, 1.0f, m->w_h.as<float>(), s));
     HIPCHK(launch_rmsnorm(m->w_h.as<float>(), 1, E, E, m->layers[0].ln1.v.as<float>(), m->c.rms_norm_eps, m->w_xn.p, E, s));
     const int nl = (int)m->layers.size();
-    for (int l = 0; l < nl; ++l)
-        VRCHK(gen_layer(m, l, 1, true, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : m->final_norm.v.as<float>(), s));
+    if (m->p_grid > 0) {
+        VRCHK(persist_layers(m, s));               // all layers in one launch; leaves the lm_head's A row in w_xn like the loop below
+    } else {
+        for (int l = 0; l < nl; ++l)
+            VRCHK(gen_layer(m, l, 1, true, l + 1 < nl ? m->layers[l + 1].ln1.v.as<float>() : m->final_norm.v.as<float>(), s));
+    }
     VRCHK(gen_head(m, nullptr, true, s));
     if (sampled)
         HIPCHK(launch_sample(gen_logits(m, m->cur), m->V, gen_seen(m, m->cur), penalty, temperature, seed, 0, m->w_tok.as<int>(),
@@ -412,7 +488,7 @@ extern "C" int vg_sample(vg_model_t m, float temperature, float repetition_penal
     HIPCHK(hipMemcpyAsync(token_out, m->w_tok.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     m->tok_on_device = true;
-    return VR_OK;
+    return persist_check(m);
 }
 
 // ---- free-running generation ------------------------------------------------------------------------------------
@@ -478,7 +554,7 @@ extern "C" int vg_run_token(vg_model_t m, int32_t index, int32_t* token) {
     VRCHK(set_dev(m->device));
     HIPCHK(hipEventSynchronize(m->run_ev[index % GEN_RUN_RING]));
     *token = m->h_tokens[index % GEN_RUN_RING];
-    return VR_OK;
+    return persist_check(m);
 }
 
 extern "C" int vg_run_end(vg_model_t m) {
@@ -499,7 +575,7 @@ extern "C" int vg_select(vg_model_t m, int32_t slot) {
     m->len = m->slot_len[slot]; m->have_logits = m->slot_logits[slot] != 0;
     m->tok_on_device = false;
     drop_graph(m);
-    return VR_OK;
+    return persist_setup(m);                       // the layer table points at the slot's caches
 }
 
 // one decoder layer of a batched decode step: n rows, one per sequence, each with its own cache rows
@@ -652,7 +728,7 @@ extern "C" int vg_logits(vg_model_t m, float* out, void* stream) {
     VRCHK(end_run(m));
     HIPCHK(hipMemcpyAsync(out, gen_logits(m, m->cur), (size_t)m->V * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    return VR_OK;
+    return persist_check(m);
 }
 
 extern "C" int vg_cache_len(vg_model_t m, int32_t* len) {

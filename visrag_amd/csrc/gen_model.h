@@ -51,6 +51,10 @@ struct vg_model_s {
     int run_steps = 0;                  // steps enqueued in the current run
     int* h_tokens = nullptr;            // pinned ring [GEN_RUN_RING] the sampled tokens are copied into
     hipEvent_t run_ev[8] = {};          // run_ev[i % 8]: step i's token has landed
+    // the decode step's persistent layer kernel (gen_persist.hip): layer table for the CURRENT slot, barrier words, host-mapped abort flag
+    DevBuf p_table, p_sync, p_ss;
+    unsigned* p_abort = nullptr;        // hipHostMalloc'd
+    int p_grid = 0;                     // 0: the shape / device does not take the kernel (separate launches instead)
     VisionTower* vis = nullptr;         // attached by vg_vision_create
     int vis_tokens = 0;                 // embedding rows the last vg_vision_encode left in w_emb (image-token order)
 };

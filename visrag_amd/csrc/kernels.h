@@ -110,7 +110,30 @@ struct GenBatch {
     int q_in[16 * GEN_ATT_SPLITS];                   // the item's first q row (128-wide rows: row * heads)
     int sampled[16];                                 // vg_sample_batch: the sampled tokens
 };
-hipError_t launch_decode_begin(GenState* st, int q_rows, hipStream_t s);   // q_rows: query rows per KV range (the GQA group size)
+hipError_t launch_decode_begin(GenState* st, int q_rows, hipStream_t s);
+// All decoder layers of ONE decode step (one sequence) as one persistent launch, a workgroup per CU (gen_persist.hip).
+struct PersistLayer {
+    const void *wqkv, *wo, *wgu, *wd;       // bf16 [n_pad][k_pad] (gate / up rows interleaved in blocks of 16: EPI_SWIGLU's layout)
+    const float* bqkv;                      // f32 [QKV] or null
+    const float *g1, *g2;                   // input / post-attention norm weights of this layer
+    void *kc, *vc;                          // the sequence's K / V cache of this layer: bf16 [rows][KVD]
+};
+struct PersistArgs {
+    const PersistLayer* layers; int n_layers;
+    int E, QKV, QD, KVD, H, KV, Ip, N2;     // hidden, q|k|v columns, q columns, KV columns, heads, KV heads, act row length, gate|up rows (padded)
+    int ldw_qkv, ldw_o, ldw_gu, ldw_d;      // row lengths (k_pad) of the four weight matrices
+    int ks_qkv, ks_o, ks_d;                 // K splits (gate|up is unsplit: SwiGLU in its epilogue)
+    float eps;
+    const float* g_final;                   // the model's final norm weight
+    float* h; void* xn;                     // residual row f32 [E]; in: the first layer's normalised row (bf16), out: the lm_head's
+    float* planes; void* act; void* attp; float* lse; float* ss;   // split-K planes, SwiGLU row, partial attention rows + lse, 16 row sums of squares
+    const GenState* st; const float* inv_freq; int sec_t, sec_h;
+    unsigned long long* sync;               // 128 words, zeroed once (barrier counters live across launches)
+    unsigned* abort_host;                   // host-mapped flag: a barrier timed out
+};
+hipError_t launch_decode_persist(const PersistArgs& a, int grid, hipStream_t s);
+int decode_persist_occupancy();             // workgroups per CU the kernel fits (0: never launch it)
+   // q_rows: query rows per KV range (the GQA group size)
 // multimodal RoPE on q (in place into q_out) and k (into the K cache at rows cache_row0 + t), v copied into the V
 // cache; head_dim 128; pos3 = [3][pos_stride] ints (temporal, height, width); inv_freq f32 [64]; source = bf16 qkv rows
 // or (parts != null) fp32 split-K planes + bias; cu_kv (optional) receives {0, cache_row0 + T}
