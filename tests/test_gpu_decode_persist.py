@@ -44,44 +44,48 @@ def _walk(llm, ids, steps, tokens):
 
 @pytest.mark.parametrize("shape", ["tiny", "7b"])
 def test_persistent_decode_equals_separate_launches(shape):
+    """Teacher-forced decode steps from prompts of several lengths (1 to 11 KV ranges; cache lengths on both sides of the
+    range and tile boundaries), then free-running captured steps with temperature: equal logits, equal tokens.  (The two
+    paths share their small arithmetic through csrc/gen_math.h: a rotation fused differently in the two kernels once showed
+    up as one decode step in a few hundred with logits 2e-3 of their scale apart.)"""
     from visrag_amd.evisrag import SamplingParams
     if shape == "tiny":
         cfg = QwenGenConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=1, intermediate_size=704,
                             vocab_size=1024, mrope_section=(16, 24, 24))
         kw = dict(max_model_len=512, max_prefill=256)
-        n_prompt, steps = 150, 12
+        lens, steps = [60, 127, 150, 255], 12
     else:
         cfg = QwenGenConfig(num_hidden_layers=2)
         kw = dict(max_model_len=2048, max_prefill=1536)
-        n_prompt, steps = 1405, 10
-    rng = np.random.default_rng(1)
-    ids = rng.integers(16, cfg.vocab_size, n_prompt).tolist()
-    toks = rng.integers(16, cfg.vocab_size, steps).tolist()
-    a = _llm(cfg, False, **kw)
-    ref = _walk(a, ids, steps, toks)
-    # free-running steps of the separate-launch model, for the captured-graph comparison below
+        lens, steps = [128, 383, 640, 1100, 1405], 8
+    prompts = {}
+    for n in lens:
+        rng = np.random.default_rng(n)
+        prompts[n] = (rng.integers(16, cfg.vocab_size, n).tolist(), rng.integers(16, cfg.vocab_size, steps).tolist())
     sp = SamplingParams(temperature=0.7, repetition_penalty=1.05, max_tokens=8, seed=11)
-    a.prefill(ids)
-    first = a.sample(sp, 0)
-    a.run_begin(n_prompt, sp)
-    for _ in range(6):
-        a.run_step()
-    ref_run = [a.run_token(i) for i in range(6)]
-    a.run_end()
+    n_run = lens[-1]
+
+    def run(llm):
+        walks = {n: _walk(llm, prompts[n][0], steps, prompts[n][1]) for n in lens}
+        llm.prefill(prompts[n_run][0])
+        first = llm.sample(sp, 0)
+        llm.run_begin(n_run, sp)                     # the captured step (one graph launch per token)
+        for _ in range(6):
+            llm.run_step()
+        toks = [first] + [llm.run_token(i) for i in range(6)]
+        llm.run_end()
+        return walks, toks
+
+    a = _llm(cfg, False, **kw)
+    ref, ref_run = run(a)
     a.close()
     del a
     torch.cuda.empty_cache()
     b = _llm(cfg, True, **kw)
-    got = _walk(b, ids, steps, toks)
-    for k, (x, y) in enumerate(zip(ref, got)):
-        assert np.isfinite(y).all(), k
-        assert np.array_equal(x, y), (shape, k, float(np.abs(x - y).max()), float(np.abs(x).max()))
-    # the captured step (one graph launch per token) runs the same kernel
-    b.prefill(ids)
-    assert b.sample(sp, 0) == first
-    b.run_begin(n_prompt, sp)
-    for _ in range(6):
-        b.run_step()
-    assert [b.run_token(i) for i in range(6)] == ref_run
-    b.run_end()
+    got, got_run = run(b)
     b.close()
+    for n in lens:
+        for k, (x, y) in enumerate(zip(ref[n], got[n])):
+            assert np.isfinite(y).all(), (n, k)
+            assert np.array_equal(x, y), (shape, n, k, float(np.abs(x - y).max()), float(np.abs(x).max()))
+    assert got_run == ref_run

@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # every fmaxf of an MFMA result is preceded by a canonicalising v_max_f32 x, x (32 extra VALU per tile);
 # same for the clamp of the GELU epilogue (gemm*.hip: one v_max per output value).
 FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nans"], "gemm192.hip": ["-fno-honor-nans"],
-              "gemm256w.hip": ["-fno-honor-nans"]}
+              "gemm256w.hip": ["-fno-honor-nans"], "gen_persist.hip": ["-fno-honor-nans"]}
 # gemm256w.hip hand-allocates the accumulation registers inside asm statements; hipcc only sees them as clobbers,
 # so if it ever runs out of VGPRs there it parks the overflow in registers that hold results.  The build checks
 # the generated code: outside the kernel's own asm there must be no accumulation-register traffic at all.

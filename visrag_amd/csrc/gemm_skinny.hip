@@ -13,6 +13,7 @@
 // nine loads per K-step (eight 8-row groups of its 64 W rows + one 8-row group of A — waves 2 and 3 repeat the
 // groups of waves 0 and 1) so one `vmcnt(18)` fits all; K-steps past the end point out of the descriptor's range.
 #include "gemm_core.h"
+#include "gen_math.h"
 #include "kernels.h"
 
 namespace vr {
@@ -104,8 +105,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyComb
 #pragma unroll
             for (int t = 0; t < GEN_ATT_SPLITS; ++t) {
                 const float w = exp2f(cl[t] - mx);              // (ranges past the last: 2^-inf = 0)
-                num += w * cpv[t];
-                den += w;
+                merge_range(num, den, w, cpv[t]);
             }
             *reinterpret_cast<bf16_t*>(smem + wave * SK_STAGE + SK_W_BYTES + lane * 2) = f2bf(num / den);
         }

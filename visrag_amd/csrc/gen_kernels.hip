@@ -4,6 +4,7 @@
 // file:line map); the reference itself delegates it to vLLM (src/evisrag/predict.py:112-123,147).
 // Roofline: both are HBM/latency bound and tiny (a few KiB to ~600 KiB per call).
 #include "common.h"
+#include "gen_math.h"
 #include "kernels.h"
 
 namespace vr {
@@ -68,9 +69,7 @@ __global__ __launch_bounds__(256) void mrope_cache_kernel(const bf16_t* __restri
         const int c = lane < sec_t ? 0 : (lane < sec_t + sec_h ? 1 : 2);
         const float pos = (float)pos3[c * pos_stride + t];
         const float ang = pos * inv_freq[lane];                                          // inv_freq[p] = theta^(-2p/128), host-made
-        const float cs = cosf(ang), sn = sinf(ang);
-        const float r1 = x1 * cs - x2 * sn, r2 = x2 * cs + x1 * sn;                      // x*cos + rotate_half(x)*sin
-        x1 = r1; x2 = r2;
+        rope_rotate(x1, x2, cosf(ang), sinf(ang));                                       // x*cos + rotate_half(x)*sin
     }
     const size_t crow = cache_rows ? (size_t)cache_rows[t] : (size_t)(cache_row0 + t);   // (batched decode: one cache per row)
     bf16_t* dst;
@@ -323,8 +322,7 @@ __global__ void attn_combine_kernel(const bf16_t* __restrict__ part, const float
 #pragma unroll
     for (int s = 0; s < GEN_ATT_SPLITS; ++s) {
         const float w = exp2f(l[s] - mx);
-        num += w * pv[s];
-        den += w;
+        merge_range(num, den, w, pv[s]);
     }
     out[h * 128 + d] = f2bf(num / den);
 }

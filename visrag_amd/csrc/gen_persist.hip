@@ -34,6 +34,7 @@
 // Roofline: HBM (the layers' weights, 13.1 GB for the 7B model, once per token).
 #include "attention_body.h"
 #include "gemm_core.h"
+#include "gen_math.h"
 #include "kernels.h"
 
 namespace vr {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
             stc4(hrs, co, v);
         }
         rv = v;
-        const float s = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        const float s = wave_sum(sumsq4(v));
         if (lane == 0) stc(p.ss + bid, s);
     };
     // rstd of the row from the 16 partial sums, added in index order; every wave for itself (no LDS, no barrier)
@@ -361,9 +362,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
                             const int c = lane < p.sec_t ? 0 : (lane < p.sec_t + p.sec_h ? 1 : 2);
                             const float pos = (float)st->pos[c];
                             const float ang = pos * p.inv_freq[lane];
-                            const float cs = cosf(ang), sn = sinf(ang);
-                            const float r1 = y1 * cs - y2 * sn, r2 = y2 * cs + y1 * sn;
-                            y1 = r1; y2 = r2;
+                            rope_rotate(y1, y2, cosf(ang), sinf(ang));
                         }
                         bf16_t* dst;
                         if (sl < G) dst = qrows + sl * 128;
@@ -426,8 +425,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
 #pragma unroll
                     for (int t = 0; t < GEN_ATT_SPLITS; ++t) {
                         const float e = exp2f(cl[t] - mx);
-                        num += e * cpv[t];
-                        den += e;
+                        merge_range(num, den, e, cpv[t]);
                     }
                     reinterpret_cast<bf16_t*>(abuf)[cc] = f2bf(num / den);
                 }

@@ -4,6 +4,7 @@
 //   MiniCPMRMSNorm: modeling_minicpm.py:119-136 (fp32 mean-square, rsqrt(var+eps), * weight)
 // Roofline: HBM (reads 4 B, writes 2 B per element).
 #include "common.h"
+#include "gen_math.h"
 #include "kernels.h"
 
 namespace vr {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_accum_row_kernel(float* __restri
         xr[c] = v;
     }
     if (!out) return;
-    float s = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    float s = wave_sum(sumsq4(v));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     float tot = 0.f;
