@@ -1,8 +1,6 @@
 """Per-token summary of a rocprofv3 --kernel-trace run of tools/evisrag_bench.py (rocpd sqlite):
-    python tools/gen_prof_summary.py <results.db> [out.txt] [skip=0]
-Takes ten decode steps ending `skip` tokens before the last one (a step = everything between two sample_final_kernel
-launches; evisrag_bench ends with one host-driven answer, so skip = answer_tokens + 2 lands in the captured steps of the
-query before it) and prints wall time, kernel-busy time and the per-kernel shares per token, plus the
+    python tools/gen_prof_summary.py <results.db> [out.txt]
+Takes ten consecutive full decode steps (a step = everything between two sample_final_kernel launches) and prints wall time, kernel-busy time and the per-kernel shares per token, plus the
 weight-streaming GEMM by grid size (its four per-layer shapes and the lm_head)."""
 import sqlite3
 import sys
@@ -15,13 +13,19 @@ def main():
     rows = c.execute("select name, start, end, grid_x from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if "sample_final" in r[0]]
     n = 10
-    skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    a, b = idx[-n - 2 - skip], idx[-2 - skip]
+    # a decode step = the launches between two sample_final kernels.  The run holds captured steps (the same launches every
+    # token), host-driven steps and prefills; take the LAST window of n consecutive intervals that all have the most common
+    # launch count among full decode steps (> 100 launches: whole-model steps, not the bench's short layers-only probes)
+    counts = [idx[i + 1] - idx[i] for i in range(len(idx) - 1)]
+    full = [c_ for c_ in counts if c_ > 100]
+    mode = max(set(full), key=full.count)
+    start = next(i for i in range(len(counts) - n, -1, -1) if all(c_ == mode for c_ in counts[i:i + n]))
+    a, b = idx[start], idx[start + n]
     seg = rows[a:b + 1]
     wall = (seg[-1][2] - seg[0][2]) / 1e3
     busy = sum(r[2] - r[1] for r in seg[1:]) / 1e3
-    print(f"# decode steps: {n} tokens ending {skip} before the last, per token: wall {wall / n:.1f} us, kernels busy {busy / n:.1f} us, "
-          f"{(len(seg) - 1) / n:.0f} launches", file=out)
+    print(f"# decode steps: {n} consecutive tokens (steps {start}..{start + n - 1} of {len(counts)} in the run), per token: wall {wall / n:.1f} us, "
+          f"kernels busy {busy / n:.1f} us, {(len(seg) - 1) / n:.0f} launches", file=out)
     d = defaultdict(lambda: [0, 0.0])
     for r in seg[1:]:
         k = r[0] if len(r[0]) < 110 else r[0][:107] + "..."

@@ -17,7 +17,7 @@ python $R/tools/prof_summary.py $(find /tmp/rp3 -name '*.db' | head -1) $O/r${N}
 python $R/tools/search_bench.py 1000 128 16 1 > $O/r${N}_search_bench.txt 2>/dev/null   # sweep TF/s and stream-kernel index GB/s
 python $R/tools/search_diag.py 100000 2304 1,16,256,1000 > $O/r${N}_search_stages.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats -d /tmp/rp4 -o g -- python $R/tools/evisrag_bench.py 5 64 2 1 > $O/r${N}_generate_bench.json 2>/tmp/rp4.log
-python $R/tools/gen_prof_summary.py $(find /tmp/rp4 -name '*.db' | head -1) $O/r${N}_generate_kernel_trace.txt 66
+python $R/tools/gen_prof_summary.py $(find /tmp/rp4 -name '*.db' | head -1) $O/r${N}_generate_kernel_trace.txt
 bash $R/tools/pmc_mfma.sh > /tmp/pmc_m.log 2>&1; cp $R/gpurun_out/pmc/mfma_util.txt $O/r${N}_pmc_mfma_util.txt
 bash $R/tools/pmc_traffic.sh > /tmp/pmc_t.log 2>&1; cp $R/gpurun_out/pmc/table.txt $O/r${N}_pmc_traffic.txt; cp $R/gpurun_out/pmc/traffic.json $O/r${N}_traffic.json
 tail -c 400 $O/r${N}_bench_n1.json; echo; cat $O/r${N}_search_bench.txt; head -12 $O/r${N}_encode_only_kernel_trace.txt | cut -c1-140; ls -la $O
