@@ -117,8 +117,6 @@ struct Barrier {
 
 }  // namespace
 
-int decode_persist_smem() { return PS_SMEM; }
-
 __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const abuf = smem + PS_RING;
