@@ -167,29 +167,35 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, VR_LDS(stg + d * 1024), 16, lof + kb, (unsigned)rfl((int)(((unsigned)wave * 8u + d) * rg)), 0, PS_W_AUX);
     };
     // the first three K-steps of unit u, requested by waves 0..2 for all four waves' rows (96 instructions, 32 each)
-    auto prefetch = [&](const Unit& u) {
+    // the first K-steps of unit u, requested by waves 0..2 for all four waves' rows (32 instructions per K-step): three when the
+    // phase in between needs stage 3 of the ring (the attention tiles, the range merge), else all four stages
+    auto prefetch_n = [&](const Unit& u, auto steps_c) {
+        constexpr int STEPS = decltype(steps_c)::value;
         if (!u.on || wave == 3) return;
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned long long)u.whi << 32 | u.wlo), 0, 0x7FFFFFFF, 0x00020000);
         const unsigned lof = (unsigned)(lane >> 3) * u.ldw2 + lchunk;
         const unsigned rg = u.ldw2 * 8u;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < (STEPS * 32 + 2) / 3; ++i) {
             const int j = wave + 3 * i, kt = j >> 5, rgi = j & 31;          // K-step, 8-row group of the 256 rows
+            if (j >= STEPS * 32) continue;
             const unsigned kb = kt < u.nk ? (unsigned)kt * (GEMM_BK * 2) : PS_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, VR_LDS(smem + kt * PS_STAGE + rgi * 1024), 16, lof + kb, (unsigned)rfl((int)((unsigned)rgi * rg)), 0, PS_W_AUX);
         }
     };
+    auto prefetch = [&](const Unit& u) { prefetch_n(u, std::integral_constant<int, 3>{}); };
+    auto prefetch4 = [&](const Unit& u) { prefetch_n(u, std::integral_constant<int, 4>{}); };
     // the K loop over a prefetched unit with the A row (row 0 of the MFMA's 16) in abuf: gemm_skinny.hip's MFMA order
     const int ch0 = (fq ^ (fr & 7)) << 4, ch1 = ((4 + fq) ^ (fr & 7)) << 4;
-    auto stream = [&](const Unit& u, f32x4 (&acc)[4]) {
+    auto stream = [&](const Unit& u, f32x4 (&acc)[4], bool pre4 = false) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // K-steps 0..2 are in the ring (prefetched before the barrier and waited for here: every wave starts the loop with an
+        // K-steps 0..2 (0..3: pre4) are in the ring (prefetched before the barrier and waited for here: every wave starts the loop with an
         // empty request queue, so its vmcnt(16) keeps meaning "my loads of step kt have landed")
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int kt = 0; kt < u.nk; ++kt) {
             VR_WAIT_VM_BARRIER(16);                 // K-step kt has landed everywhere; everyone is done with stage (kt - 1) % 4
-            w_issue(u, kt + 3);                     // (past the end: zeros into a dead stage, no traffic — the count above stays valid)
+            if (!(pre4 && kt == 0)) w_issue(u, kt + 3);   // (four steps prefetched: step 3 is there.  Past the end: zeros into a dead stage, no traffic — the count above stays valid)
             const char* wr = smem + (kt & 3) * PS_STAGE + (wave * 64 + fr) * 128;
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(abuf + kt * 128 + fq * 16);
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(abuf + kt * 128 + 64 + fq * 16);
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
 
     int* const flag = reinterpret_cast<int*>(misc + 8);
     Unit next = unit_of(p.layers[0].wqkv, p.ldw_qkv, p.QKV, p.E, p.ks_qkv);
-    prefetch(next);
+    prefetch4(next);
     for (int l = 0; l < p.n_layers && !bar.dead; ++l) {
         // (pointers from the table made wave-uniform by hand: descriptors built from them must sit in SGPRs)
         auto uptr = [&](const void* q) {
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
                 } else {
                     norm_to_abuf(L.g1, u.kof, u.nk * 64);
                 }
-                stream(u, acc);
+                stream(u, acc, true);
                 store_plane(u, acc, p.planes, p.QKV);
             }
             next = unit_of(L.wo, p.ldw_o, p.E, p.QD, p.ks_o);
@@ -335,12 +341,12 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
                         off[q] = (unsigned)(col + lane) * 4u;
                     }
                     const unsigned ps = (unsigned)p.QKV * 4u;
-                    for (int sp = 0; sp < p.ks_qkv; sp += 8) {
-                        float a[3][8], c2[3][8];
+                    for (int sp = 0; sp < p.ks_qkv; sp += 16) {
+                        float a[3][16], c2[3][16];
 #pragma unroll
                         for (int q = 0; q < 3; ++q)
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
+                            for (int i = 0; i < 16; ++i) {
                                 const unsigned po = (unsigned)min(sp + i, p.ks_qkv - 1) * ps;
                                 a[q][i] = ldc1(prs, off[q] + po);
                                 c2[q][i] = ldc1(prs, off[q] + po + 256u);
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
 #pragma unroll
                         for (int q = 0; q < 3; ++q)
 #pragma unroll
-                            for (int i = 0; i < 8; ++i)
+                            for (int i = 0; i < 16; ++i)
                                 if (sp + i < p.ks_qkv) { x1[q] += a[q][i]; x2[q] += c2[q][i]; }
                     }
 #pragma unroll
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
             }
             next = unit_of(L.wgu, p.ldw_gu, p.N2, p.E, 1);
             bar.arrive();
-            prefetch(next);
+            prefetch4(next);
             bar.wait(flag);
         }
         // ---------------- R (o planes), then gate | up with SwiGLU in the epilogue
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
             const Unit u = next;
             if (u.on) {
                 norm_to_abuf(L.g2, 0, p.E);
-                stream(u, acc);
+                stream(u, acc, true);
                 if (fr == 0) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
             }
             next = unit_of(L.wd, p.ldw_d, p.E, p.Ip, p.ks_d);
             bar.arrive();
-            prefetch(next);
+            prefetch4(next);
             bar.wait(flag);
         }
         // ---------------- down projection
@@ -472,13 +478,13 @@ __global__ __launch_bounds__(256) void decode_persist_kernel(PersistArgs p) {
                 for (int c = tid; c * 2 < u.nk * 64; c += 256)
                     reinterpret_cast<unsigned*>(abuf)[c] = ldc(reinterpret_cast<const unsigned*>(p.act) + u.kof / 2 + c);
                 __syncthreads();
-                stream(u, acc);
+                stream(u, acc, true);
                 store_plane(u, acc, p.planes, p.E);
             }
             const bool more = l + 1 < p.n_layers;
             if (more) next = unit_of(p.layers[l + 1].wqkv, p.ldw_qkv, p.QKV, p.E, p.ks_qkv);
             bar.arrive();
-            if (more) prefetch(next);
+            if (more) prefetch4(next);
             bar.wait(flag);
         }
     }
