@@ -463,3 +463,40 @@ def test_wide_band_is_rescored_inside_the_merge(nq):
     st = ix.search_stats()
     _assert_ids_equal_fp64(ids, sc, C, Q, k)
     assert st["exact_pass"] == 0 and st["regathered"] >= 1, st
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_search_random_shapes_and_structure_vs_fp64(seed):
+    """Seeded random (rows, queries, width, k) with random structure thrown in — exact duplicate rows, near-duplicate
+    clusters at 1e-5 .. 1e-3, queries that ARE index rows, two index parts — against an fp64 brute force: identical
+    ids up to fp32 summation noise, every query certified or sent through the exact pass."""
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.choice([64, 128, 192, 256, 384, 768, 1152, 2304]))
+    nd = int(rng.choice([1, 9, 130, 257, 1000, 4097, 12000, 30011]))
+    nq = int(rng.choice([1, 2, 7, 16, 17, 33, 128, 129, 300]))
+    k = int(rng.choice([1, 3, 10, 16, 26, 27, 60, 100]))
+    C = _unit(nd, dim, 2000 + seed)
+    Q = _unit(nq, dim, 3000 + seed)
+    if nd >= 130:
+        for _ in range(int(rng.integers(0, 4))):                     # clusters around a direction close to some query
+            n_dup = int(rng.integers(2, min(80, nd // 2)))
+            base = Q[int(rng.integers(nq))] + float(rng.uniform(0.2, 1.0)) * _unit(1, dim, int(rng.integers(1 << 30)))[0]
+            base /= np.linalg.norm(base)
+            rows = rng.choice(nd, n_dup, replace=False)
+            C[rows] = base[None, :] + float(rng.choice([0.0, 1e-5, 1e-4, 1e-3])) * rng.standard_normal((n_dup, dim)).astype(np.float32)
+            C[rows] /= np.linalg.norm(C[rows], axis=1, keepdims=True)
+        for _ in range(int(rng.integers(0, 3))):                     # a query that is an index row
+            Q[int(rng.integers(nq))] = C[int(rng.integers(nd))]
+    ix = HipIndex(dim, nd)
+    cut = int(rng.integers(0, nd + 1))
+    if cut:
+        ix.add(C[:cut])
+    if cut < nd:
+        ix.add(C[cut:])
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    kk = min(k, nd)
+    assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()
+    _assert_ids_equal_fp64(ids[:, :kk], sc[:, :kk], C, Q, kk)
+    assert st["uncertified"] == 0 and st["certified"] + st["certified_extended"] + st["exact_pass"] == nq, (st, nd, nq, dim, k)
