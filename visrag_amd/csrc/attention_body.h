@@ -24,6 +24,13 @@ template <> struct AttnCfg<128> { static constexpr int K32 = 4, TAIL = 0, DFRAGS
 // the tail of head_dim 72 / 80 (d = 64..79) as ONE 16x16x16 MFMA per fragment — half the matrix-pipe time of the
 // 16x16x32 form it replaces, whose second half multiplied zeros (72: 80 instead of 96 columns of QK^T work)
 constexpr bool TAIL16 = VR_ATTN_TAIL16 != 0;
+// wave priority: raised for a tile's PV MFMAs, dropped for its softmax (1) — with three workgroups per CU the arbiter then
+// prefers the wave that can feed the matrix pipe and fills in with the others' VALU work: ViT attention 738 -> 764 TF in
+// isolation, 5.28 -> 5.18 ms per step in the model.  (2: the other way round, 3 / 4: also raised for the score MFMAs, to
+// level 3 / 1: 766-783 TF in isolation, no better than 1 in the model.)
+#ifndef VR_ATTN_PRIO
+#define VR_ATTN_PRIO 1
+#endif
 constexpr int ATT_KV = 64;          // keys per tile
 constexpr float MAX_SLACK = 8.0f;   // log2 units the running max may lag behind before O is rescaled
 
@@ -379,10 +386,16 @@ __device__ __forceinline__ void attention_body(const AttnArgs& p, int unit, char
         bf16x8 va0[DFRAGS], va1[DFRAGS], pb[QF][2];
         float neg_m[QF];
         v_frags(Vt, 0, va0);                     // issued now, consumed after the softmax
+        if constexpr (VR_ATTN_PRIO == 1 || VR_ATTN_PRIO == 3 || VR_ATTN_PRIO == 4) __builtin_amdgcn_s_setprio(0);
+        if constexpr (VR_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         stats(s, tile, neg_m);
         exp_pack(s, neg_m, pb);
         v_frags(Vt, 1, va1);
         v_wait(va0);
+        if constexpr (VR_ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        if constexpr (VR_ATTN_PRIO == 3) __builtin_amdgcn_s_setprio(3);
+        if constexpr (VR_ATTN_PRIO == 4) __builtin_amdgcn_s_setprio(1);
+        if constexpr (VR_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         pv(va0, pb, 0);
         v_wait(va1);
         pv(va1, pb, 1);
@@ -435,6 +448,8 @@ __device__ __forceinline__ void attention_body(const AttnArgs& p, int unit, char
             constexpr int cur = decltype(cur_c)::value;
             if (tile + 1 < n_tiles) dma_tile(tile + 1, cur ^ 1);   // its slot was last read before the previous barrier
             f32x4 s[QF][4];
+            if constexpr (VR_ATTN_PRIO == 3) __builtin_amdgcn_s_setprio(3);
+            if constexpr (VR_ATTN_PRIO == 4) __builtin_amdgcn_s_setprio(1);
             scores(Ks + cur * SLOT, s);
             softmax_pv(s, Vs + cur * SLOT, tile);
             __syncthreads();                      // tile+1 landed (vmcnt(0) + barrier), slot `cur` free
