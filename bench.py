@@ -333,7 +333,7 @@ def main():
             model.set_pipeline(2)
             # (a) PIL pages in -> pickle shards out through distributed_parallel_embedding_inference: host
             #     prompt/tokenise, H2D of the pixels, GPU resize (identity for 448x448), encode, D2H, pickle
-            n_pil = 8 * B
+            n_pil = 32 * B                                    # (8 batches: the first and the last one's flush are a tenth of the run)
             pil_pages = [Image.fromarray(pages[i % pool]) for i in range(n_pil)]
             corpus = [{"id": str(i), "text": "", "image": im} for i, im in enumerate(pil_pages)]
             with tempfile.TemporaryDirectory() as td:

@@ -112,7 +112,7 @@ def prepare_item(text: str, image, tokenizer, cfg, max_inp_length: Optional[int]
             pil_slices = [image]
             ph = image_placeholder(tokenizer, cfg.query_num)
         content = ph + "\n" + content
-        slices = [np.asarray(s.convert("RGB"), dtype=np.uint8) for s in pil_slices]
+        slices = [np.asarray(s if s.mode == "RGB" else s.convert("RGB"), dtype=np.uint8) for s in pil_slices]
     ids = tokenizer.encode(content)
     if not getattr(tokenizer, "add_bos_token", True):
         ids = [tokenizer.bos_id] + list(ids)
@@ -132,13 +132,26 @@ def prepare_item(text: str, image, tokenizer, cfg, max_inp_length: Optional[int]
     return PreparedItem(input_ids=ids, image_bound=bound, slices=slices)
 
 
+_pool, _pool_workers = None, 0
+_pool_lock = __import__("threading").Lock()
+
+
 def prepare_batch(texts: Sequence[str], images: Sequence, tokenizer, cfg,
                   max_inp_length: Optional[int] = 2048, max_workers: int = 8) -> List[PreparedItem]:
     if len(texts) != len(images):
         raise ValueError("text and image lists must have the same length")
-    if len(texts) <= 1 or max_workers <= 1:
+    # The reference prepares a batch on an 8-thread pool (modeling_visrag_ret.py:98).  That pays when pages are RESIZED or
+    # sliced (Pillow's resampling releases the GIL); items that only tokenise and copy pixels — text, pages already at
+    # scale_resolution — are GIL-bound, and the pool then costs more than it buys (32 pages of 448 x 448: 36 ms on eight
+    # threads, 16 ms on one)
+    def light(im):
+        return im is None or not im or (getattr(im, "size", None) == (cfg.scale_resolution, cfg.scale_resolution))
+    if len(texts) <= 1 or max_workers <= 1 or all(light(im) for im in images):
         return [prepare_item(t, im, tokenizer, cfg, max_inp_length) for t, im in zip(texts, images)]
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max_workers) as ex:   # modeling_visrag_ret.py:98
-        return list(ex.map(lambda ti: prepare_item(ti[0], ti[1], tokenizer, cfg, max_inp_length),
-                           zip(texts, images)))
+    with _pool_lock:
+        global _pool, _pool_workers
+        if _pool is None or _pool_workers != max_workers:
+            from concurrent.futures import ThreadPoolExecutor
+            _pool, _pool_workers = ThreadPoolExecutor(max_workers=max_workers), max_workers
+        pool = _pool
+    return list(pool.map(lambda ti: prepare_item(ti[0], ti[1], tokenizer, cfg, max_inp_length), zip(texts, images)))
