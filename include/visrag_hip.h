@@ -166,27 +166,38 @@ int vr_index_size(vr_index_t ix, int64_t* n);
  * among equal scores — the ranking torch.topk sees over the fp32 matmul of
  * dense_retriever.py:28-30.  Scores are fp32 dot products of the fp32 rows.  A bf16 MFMA
  * sweep selects candidates, the survivors are re-scored in fp32, and the selection is
- * CERTIFIED per query: with |bf16 score - fp32 score| <= eps_rel * |q| * max|row| every row
- * whose bf16 score could still reach the fp32 top-k is re-scored too; a query whose candidate
- * lists cannot prove completeness (more near-ties at the k-th score than they hold) is redone
- * by an exact fp32 pass over the whole index.  The ids are the fp32 ranking's.
+ * CERTIFIED per query: with |bf16 score - fp32 score| <= eps (below) every row whose bf16 score
+ * could still reach the fp32 top-k is re-scored too; a query whose candidate lists cannot prove
+ * completeness (more near-ties at the k-th score than they hold, or a cluster of near-duplicate
+ * pages that overran them) is redone by the band pass — bf16 scores of that query against every
+ * row, ALL rows inside the error band re-scored in fp32 — and, if its band holds more than 8192
+ * rows, by an exact fp32 pass over the whole index.  The ids are the fp32 ranking's.
  *   queries [nq][dim] float32;  out_scores [nq][k] float32;  out_ids [nq][k] int64
  * (all host or all device per `on_device`).  If the index holds fewer than k rows the
  * tail is filled with score -inf, id -1.  k = 1..1000: up to 26 on the fused sweep (the
  * throughput path; --retrieve_depth 10 in eval.sh), deeper runs on GEMM + radix select. */
 int vr_index_search(vr_index_t ix, const float* queries, int32_t nq, int32_t k,
                     float* out_scores, int64_t* out_ids, int32_t on_device, void* stream);
-/* The error model of the certification: eps_rel >= 0 replaces the default bound
- * (2^-8 + 2^-18 + (2 dim + 128) 2^-24: round-to-nearest bf16 operands, fp32 accumulation,
- * worst case by Cauchy-Schwarz); eps_rel < 0 switches certification off (the bf16 top-(k+6)
- * re-scored, as in rounds 1-2: tolerance-exact); NaN restores the default. */
+/* The error model of the certification.  Default (NaN restores it): the rigorous bound for the
+ * data at hand — with dq = q - bf16(q), dd = d - bf16(d) (round to nearest even: bf16 keeps 8
+ * significand bits, unit roundoff 2^-8) and fp32 accumulation,
+ *   |bf16 score - fp32 score| <= |dq| max|d| + |q| max|dd| + |dq| max|dd|
+ *                                + (2 dim + 128) 2^-24 (|q| + |dq|) (max|d| + max|dd|)
+ * by Cauchy-Schwarz; |dq| is measured per query, max|d| and max|dd| over the index rows by
+ * vr_index_add (~3.4e-3 for unit vectors at dim 2304; the worst case over all data would be
+ * 2^-7 + 2^-16 + ... = 8.1e-3).  eps_rel >= 0: the caller's model eps_rel * |q| * max|d| instead;
+ * eps_rel < 0: certification off (the bf16 top-(k+6) re-scored, as in rounds 1-2: tolerance-exact). */
 int vr_index_set_search_eps(vr_index_t ix, float eps_rel);
-/* Queries counted since the last reset: out5[0..4] = {certified at once, certified after extended
- * re-scoring, flagged and redone by the exact pass, searched with certification off, of the second
- * group: those whose candidates had to be gathered a second time}. */
-int vr_index_search_stats(vr_index_t ix, int64_t* out5, int32_t reset);
+/* out4 = {max|d|, max|d - bf16(d)| over the rows added so far, the accumulation term
+ * (2 dim + 128) 2^-24, the worst-case relative bound 2^-7 + 2^-16 + accumulation}. */
+int vr_index_error_model(vr_index_t ix, float* out4);
+/* Queries counted since the last reset: out6[0..5] = {certified at once, certified after extended
+ * re-scoring, flagged (redone by the band pass), searched with certification off, of the second
+ * group: those whose candidates had to be gathered a second time, of the flagged: those whose band
+ * exceeded 8192 rows and went through the exact fp32 pass}. */
+int vr_index_search_stats(vr_index_t ix, int64_t* out6, int32_t reset);
 /* Per-stage HIP-event times of vr_index_search (k <= 26), summed over calls since enabling:
- * ms5 = {query conversion, threshold pre-pass, sweep, merge + re-scoring, exact pass}.
+ * ms5 = {query conversion, threshold pre-pass, sweep, merge + re-scoring, band + exact pass}.
  * While enabled every call ends with an event synchronisation. */
 int vr_index_set_search_profile(vr_index_t ix, int32_t enable);
 int vr_index_get_search_profile(vr_index_t ix, double* ms5, int64_t* calls);
@@ -205,6 +216,12 @@ int vr_topk_merge(int device_id, const float* scores, const int64_t* ids, int32_
  * all-gather's output buffer as it is) -> scores and global ids. */
 int vr_topk_merge_keys(int device_id, const uint64_t* keys, int32_t n_parts, int32_t nq, int32_t k,
                        float* out_scores, int64_t* out_ids, void* stream);
+
+/* ---- synthetic corpus (bench / test support; no reference counterpart) --------------------- */
+/* Pages first .. first + n - 1 of the deterministic synthetic corpus of visrag_amd/synth.py::synth_pages,
+ * bit-identical to the host generator, written as uint8 [n][size][size][3] to DEVICE memory.  BASELINE
+ * config 3 needs 100 000 distinct pages; there is no dataset on the box (BASELINE.json: "data": synthetic). */
+int vr_synth_pages(int device_id, uint8_t* out, int32_t n, int32_t size, int64_t seed, int64_t first, void* stream);
 
 /* ---- host pre-processing moved to the GPU ------------------- */
 /* Bicubic resize of an 8-bit RGB (HWC) image, bit-exact with Pillow's

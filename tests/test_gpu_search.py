@@ -305,15 +305,15 @@ def test_search_near_duplicate_cluster_is_exact(n_dup, nq, k):
     st = ix.search_stats()
     assert set(ids[0, :min(k, n_dup)].tolist()) <= set(cluster.tolist())
     _assert_ids_equal_fp64(ids, sc, C, Q, k)
-    assert st["certified"] + st["certified_extended"] + st["exact_pass"] == nq and st["uncertified"] == 0, st
+    assert st["certified"] + st["certified_extended"] + st["flagged"] == nq and st["uncertified"] == 0, st
     if n_dup == 20 and k == 10:
-        assert st["certified_extended"] >= 1 and st["exact_pass"] == 0, st   # 4 more candidates re-scored, no full pass
-    if n_dup >= 2000:                                                        # beyond what the merge re-scores in place (1024 rows)
-        assert st["exact_pass"] >= 1, st
+        assert st["certified_extended"] >= 1 and st["flagged"] == 0, st      # 4 more candidates re-scored, nothing behind the sweep
+    if n_dup >= 2000:                                                        # beyond what the merge re-scores in place (1024 rows):
+        assert st["band_pass"] >= 1 and st["exact_pass"] == 0, st            # the band pass re-scores the 2000, no sweep of the fp32 index
     elif k <= 26 and nq <= 16:
         # (with more than 16 queries the sweep starts from pre-pass thresholds; a cluster this dense pulls query 0's
-        # threshold up into its own error band, the lists then cannot prove completeness and the exact pass is right)
-        assert st["exact_pass"] == 0, st
+        # threshold up into its own error band, the lists then cannot prove completeness and the band pass is right)
+        assert st["flagged"] == 0, st
     # the same search with certification off is what rounds 1-2 shipped: tolerance-exact only
     ix.set_search_eps(-1.0)
     sc2, ids2 = ix.search(Q, k)
@@ -325,8 +325,9 @@ def test_search_near_duplicate_cluster_is_exact(n_dup, nq, k):
 @pytest.mark.parametrize("nd,nq,dim,k", [(20000, 1, 512, 10), (20000, 16, 2304, 10), (20000, 40, 256, 10), (30000, 300, 512, 26),
                                           (5000, 37, 256, 40), (100, 3, 64, 10), (7, 2, 64, 10)])
 def test_exact_pass_alone_matches_oracle(nd, nq, dim, k):
-    """An error model so pessimistic that NO query can be certified: every query is flagged and the exact fp32
-    pass (exact_scores_kernel + radix select) produces the whole result."""
+    """An error model so pessimistic that NO query can be certified: every query is flagged, its error band is the whole
+    index, and the result comes from the band pass alone (indices of up to 8192 rows: every row re-scored by
+    band_select_kernel) or from the exact fp32 pass alone (larger ones: exact_scores_kernel + radix select)."""
     C, Q = _unit(nd, dim, 41), _unit(nq, dim, 42)
     ix = HipIndex(dim, nd); ix.add(C)
     ix.set_search_eps(100.0)
@@ -335,7 +336,7 @@ def test_exact_pass_alone_matches_oracle(nd, nq, dim, k):
     st = ix.search_stats()
     kk = min(k, nd)
     if nd > k + 24:
-        assert st["exact_pass"] == nq, st
+        assert st["flagged"] == nq and (st["exact_pass"] == nq if nd > 8192 else st["band_pass"] == nq), st
     _assert_ids_equal_fp64(ids[:, :kk], sc[:, :kk], C, Q, kk)
     if kk < k:
         assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()
@@ -359,8 +360,8 @@ def test_random_index_is_certified_without_the_exact_pass():
     ix.search_stats(reset=True)
     sc, ids = ix.search(Q, k)
     st = ix.search_stats()
-    assert st["certified"] + st["certified_extended"] + st["exact_pass"] == nq
-    assert st["exact_pass"] <= 5, st
+    assert st["certified"] + st["certified_extended"] + st["flagged"] == nq
+    assert st["flagged"] <= 5 and st["exact_pass"] == 0, st
     rv, ri = torch.topk(Q.double() @ C.double().T, k, dim=1)
     bad = ids != ri
     assert int(bad.any(dim=1).sum()) <= 3 and (not bool(bad.any()) or float((rv - torch.gather(Q.double() @ C.double().T, 1, ids)).abs()[bad].max()) < 1e-7)
@@ -462,7 +463,7 @@ def test_wide_band_is_rescored_inside_the_merge(nq):
     sc, ids = ix.search(Q, k)
     st = ix.search_stats()
     _assert_ids_equal_fp64(ids, sc, C, Q, k)
-    assert st["exact_pass"] == 0 and st["regathered"] >= 1, st
+    assert st["flagged"] == 0 and st["regathered"] >= 1, st
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
@@ -499,4 +500,81 @@ def test_search_random_shapes_and_structure_vs_fp64(seed):
     kk = min(k, nd)
     assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()
     _assert_ids_equal_fp64(ids[:, :kk], sc[:, :kk], C, Q, kk)
-    assert st["uncertified"] == 0 and st["certified"] + st["certified_extended"] + st["exact_pass"] == nq, (st, nd, nq, dim, k)
+    assert st["uncertified"] == 0 and st["certified"] + st["certified_extended"] + st["flagged"] == nq, (st, nd, nq, dim, k)
+
+
+@pytest.mark.parametrize("nq", [1, 40])
+def test_certification_bound_holds_at_bf16_rounding_midpoints(nq):
+    """bf16 keeps 8 significand bits, its unit roundoff is 2^-8 — a bound built on 2^-9 per operand
+    (rounds 1-3: eps_rel = 2^-8 + 2^-18 + ...) certifies wrong results when components sit just below rounding midpoints.
+    Construction (dim 256, two blocks of 128 components): the query is 1/16 everywhere, scaled by (1 + 2^-8 - 2^-20) on
+    block 1 (rounds DOWN to 1/16).  Row A lives on block 1 with the same just-below-midpoint components: bf16 score 0.5,
+    fp32 score 0.5 (1 + 2^-8)^2 = 0.503917.  Forty rows B live on block 2 with bf16-exact components (1 + 2^-7) / 16:
+    bf16 = fp32 score 0.503906.  The fp32 ranking puts A FIRST; by bf16 score it is 3.9e-3 behind all forty — 5.5e-3
+    |q| max|d|, outside the old bound's band (3.95e-3), inside the true one (7.8e-3) and inside the default bound, which
+    measures the residuals of this very data."""
+    dim, nd, k = 256, 3000, 10
+    rng = np.random.default_rng(71)
+    th = np.float32(1.0 + 2.0 ** -8 - 2.0 ** -20)
+    C = (0.3 * _unit(nd, dim, 72)).astype(np.float32)                        # filler: small norms, scores ~ 0.02
+    B = np.zeros(dim, np.float32); B[128:] = np.float32((1.0 + 2.0 ** -7) / 16.0)
+    A = np.zeros(dim, np.float32); A[:128] = np.float32(1.0 / 16.0) * th
+    C[:40] = B
+    C[50] = A
+    Q = (0.5 * _unit(nq, dim, 73)).astype(np.float32)
+    Q[0] = np.float32(1.0 / 16.0)
+    Q[0, :128] *= th
+    assert A[0] != np.float32(1.0 / 16.0) and torch.tensor(A[:1]).to(torch.bfloat16).float().item() == 1.0 / 16.0    # rounds down
+    ref = C.astype(np.float64) @ Q[0].astype(np.float64)
+    assert int(np.argmax(ref)) == 50 and ref[50] - ref[0] > 5e-6              # the fp64 (and fp32) ranking: A first
+    ix = HipIndex(dim, nd); ix.add(C)
+    em = ix.error_model()
+    assert 3.8e-3 * np.linalg.norm(A) < em["max_row_bf16_residual"] < 4.0e-3 * np.linalg.norm(A), em     # |A - bf16(A)| = 2^-8 |A|
+    assert abs(em["worst_case_eps_rel"] - (2.0 ** -7 + 2.0 ** -16 + (2 * dim + 128) * 2.0 ** -24)) < 1e-6
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    assert ids[0, 0] == 50 and list(ids[0, 1:]) == list(range(9)), ids[0]
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    assert st["uncertified"] == 0
+    # the worst-case relative bound as the caller's model: the same answer
+    ix.set_search_eps(em["worst_case_eps_rel"])
+    sc2, ids2 = ix.search(Q, k)
+    assert np.array_equal(ids2, ids)
+    # what rounds 1-3 shipped as "rigorous" (2^-9 per operand): certifies the forty B rows and never looks at A
+    ix.set_search_eps(2.0 ** -8 + 2.0 ** -18 + (2 * dim + 128) * 2.0 ** -24)
+    sc3, ids3 = ix.search(Q, k)
+    assert 50 not in ids3[0]
+
+
+@pytest.mark.parametrize("n_dup,nq", [(3000, 1), (3000, 40), (3000, 300), (9000, 40)])
+def test_contiguous_near_duplicate_block_goes_through_the_band_pass(n_dup, nq):
+    """A templated document (a slide deck, a form) embedded page after page: a CONTIGUOUS block of near-duplicates — all of
+    it lands in a few half-lists of one chunk, which overflow, and the pre-pass threshold sits inside the block.  The merge
+    cannot certify; the band pass scores the flagged queries against every row (bf16 GEMM), re-scores the whole band in fp32
+    and returns the fp32 ranking — without sweeping the fp32 index once per 8 queries.  More than 8192 rows inside the band:
+    the exact fp32 pass."""
+    dim, nd, k = 2304, 24000, 10
+    C = _unit(nd, dim, 81)
+    Q = _unit(nq, dim, 82)
+    rng = np.random.default_rng(83)
+    base = Q[0] + 0.5 * _unit(1, dim, 84)[0]
+    base /= np.linalg.norm(base)
+    C[6000:6000 + n_dup] = base[None, :] + 1e-4 * rng.standard_normal((n_dup, dim)).astype(np.float32)
+    C[6000:6000 + n_dup] /= np.linalg.norm(C[6000:6000 + n_dup], axis=1, keepdims=True)
+    ix = HipIndex(dim, nd); ix.add(C)
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    assert set(ids[0].tolist()) <= set(range(6000, 6000 + n_dup))
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    assert st["uncertified"] == 0 and st["certified"] + st["certified_extended"] + st["flagged"] == nq, st
+    if n_dup <= 8192:
+        assert st["band_pass"] >= 1 and st["exact_pass"] == 0, st
+    else:
+        assert st["exact_pass"] >= 1, st
+    # the packed-key output of the multi-GPU exchange takes the same route
+    from visrag_amd.retriever import unpack_keys_host
+    keys = ix.search_keys(torch.from_numpy(Q).cuda(), k, id_offset=7)
+    us, ui = unpack_keys_host(keys.cpu().numpy())
+    assert np.array_equal(ui, ids + 7) and np.array_equal(us, sc)

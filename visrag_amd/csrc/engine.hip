@@ -1074,18 +1074,19 @@ extern "C" int vr_model_get_profile(vr_model_t m, int32_t cls, double* total_ms,
 }
 
 // --------------------------------------------------------------------------------- index ---
+constexpr int CERT_WORDS = 32, CERT_FLAG = 2, CERT_FLAG2 = 3, CERT_STATS = 4, CERT_NSTATS = 6;
 struct vr_index_s {
     int device = 0, dim = 0;
     int64_t cap = 0, n = 0;
     DevBuf f32, bf16;                 // [cap_pad][dim]
     DevBuf q32, qbf, cs, ci, ck, os, oi, ok, thr, sbuf;  // query staging / candidates / outputs / thresholds / score rows
     int64_t qcap = 0, ccap = 0, kcap = 0;
-    // certification state (search_common.h): word 0 = largest row norm (f32), word 1 = flag count,
-    // words 2..5 = query counters {certified at once, after extended re-scoring, flagged, uncertified mode}, word 6 = queries
-    // whose candidates were gathered a second time
-    DevBuf cert, flags;
+    // certification state (search_common.h), 32 words: f32 [0] largest row norm, [1] largest bf16 rounding residual of a row;
+    // int [2] flag count, [3] second-level flag count (exact fp32 pass); u32 [4..9] query counters {certified at once, after
+    // extended re-scoring, flagged, uncertified mode, candidates gathered a second time, of the flagged: exact fp32 pass}
+    DevBuf cert, flags, flagq;        // flags: int flag_list[fcap] | int flag2_list[fcap] | f32 flag_tau[fcap]; flagq: bf16 [fcap][dim]
     int64_t fcap = 0;
-    float eps_rel = -2.f;             // -2: the rigorous default for `dim`; < 0 otherwise: certification off
+    float eps_rel = -2.f;             // -2: the rigorous data-dependent default; >= 0: the caller's eps_rel |q| max|d|; else off
     // per-stage HIP events (vr_index_set_search_profile): convert | thresholds | sweep | merge | exact pass
     bool prof_on = false;
     hipEvent_t prof_ev[SEARCH_PROF_EVENTS] = {};
@@ -1103,7 +1104,7 @@ extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_
     const int64_t cp = pad256l(capacity);
     int r = ix->f32.alloc((size_t)cp * dim * 4);
     if (r == VR_OK) r = ix->bf16.alloc((size_t)cp * dim * 2);
-    if (r == VR_OK) r = ix->cert.alloc(64);
+    if (r == VR_OK) r = ix->cert.alloc(CERT_WORDS * 4);
     if (r != VR_OK) { ix->f32.free(); ix->bf16.free(); ix->cert.free(); delete ix; return r; }
     *out = ix;
     return VR_OK;
@@ -1114,7 +1115,7 @@ extern "C" int vr_index_destroy(vr_index_t ix) {
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&ix->f32, &ix->bf16, &ix->q32, &ix->qbf, &ix->cs, &ix->ci, &ix->ck, &ix->os, &ix->oi, &ix->ok, &ix->thr,
-                      &ix->sbuf, &ix->cert, &ix->flags})
+                      &ix->sbuf, &ix->cert, &ix->flags, &ix->flagq})
         b->free();
     for (hipEvent_t e : ix->prof_ev) if (e) (void)hipEventDestroy(e);
     delete ix;
@@ -1125,7 +1126,7 @@ extern "C" int vr_index_reset(vr_index_t ix) {
     if (!ix) return fail(VR_ERR_INVALID, "NULL index");
     VRCHK(set_dev(ix->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(ix->cert.p, 0, 4));          // largest row norm
+    HIPCHK(hipMemset(ix->cert.p, 0, 8));          // largest row norm, largest rounding residual
     ix->n = 0;
     return VR_OK;
 }
@@ -1145,7 +1146,7 @@ extern "C" int vr_index_add(vr_index_t ix, const float* reps, int64_t n, int32_t
     float* dst = ix->f32.as<float>() + (size_t)ix->n * ix->dim;
     HIPCHK(hipMemcpyAsync(dst, reps, (size_t)n * ix->dim * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     HIPCHK(launch_f32_to_bf16(dst, (char*)ix->bf16.p + (size_t)ix->n * ix->dim * 2, (size_t)n * ix->dim, s));
-    HIPCHK(launch_row_norm_max(dst, n, ix->dim, ix->cert.as<float>(), s));      // |d| of the search's error bound
+    HIPCHK(launch_row_norm_max(dst, n, ix->dim, ix->cert.as<float>(), s));      // max |d|, max |d - bf16(d)|: the search's error bound
     if (!on_device) HIPCHK(hipStreamSynchronize(s));
     ix->n += n;
     return VR_OK;
@@ -1158,14 +1159,24 @@ extern "C" int vr_index_set_search_eps(vr_index_t ix, float eps_rel) {
     return VR_OK;
 }
 
-extern "C" int vr_index_search_stats(vr_index_t ix, int64_t* out4, int32_t reset) {     // out4: FIVE words, see the header
+extern "C" int vr_index_search_stats(vr_index_t ix, int64_t* out6, int32_t reset) {     // out6: SIX words, see the header
+    if (!ix || !out6) return fail(VR_ERR_INVALID, "NULL argument");
+    VRCHK(set_dev(ix->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned w[CERT_NSTATS];
+    HIPCHK(hipMemcpy(w, ix->cert.as<unsigned>() + CERT_STATS, CERT_NSTATS * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < CERT_NSTATS; ++i) out6[i] = w[i];
+    if (reset) HIPCHK(hipMemset(ix->cert.as<unsigned>() + CERT_STATS, 0, CERT_NSTATS * 4));
+    return VR_OK;
+}
+
+extern "C" int vr_index_error_model(vr_index_t ix, float* out4) {
     if (!ix || !out4) return fail(VR_ERR_INVALID, "NULL argument");
     VRCHK(set_dev(ix->device));
     HIPCHK(hipDeviceSynchronize());
-    unsigned w[5];
-    HIPCHK(hipMemcpy(w, ix->cert.as<unsigned>() + 2, 20, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 5; ++i) out4[i] = w[i];
-    if (reset) HIPCHK(hipMemset(ix->cert.as<unsigned>() + 2, 0, 20));
+    HIPCHK(hipMemcpy(out4, ix->cert.p, 8, hipMemcpyDeviceToHost));
+    out4[2] = search_acc_rel(ix->dim);
+    out4[3] = search_default_eps_rel(ix->dim);
     return VR_OK;
 }
 
@@ -1201,10 +1212,13 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
     hipStream_t s = (hipStream_t)stream;
     const int dim = ix->dim;
     const int64_t ldS = pad256l(std::max<int64_t>(ix->n, 1));
-    // queries per pass: the exact pass reserves one fp32 score row per query of a pass (1 GiB at most)
-    int64_t qblk = bigk ? 256 : std::max<int64_t>(256, ((int64_t)1 << 28) / ldS / 256 * 256);
-    qblk = std::min<int64_t>(qblk, pad256l(nq));
+    // queries per pass: the deep path's GEMM writes one fp32 score row per query; the fused path's candidate scratch grows
+    // with the pass (128 KiB of half-lists per query at 100k rows)
+    int64_t qblk = bigk ? 256 : 4096;
     const int64_t nqp = pad256l(std::min<int64_t>(nq, qblk));
+    // score rows of the fallback passes (band pass / exact pass over the FLAGGED queries, search_band.hip): a bounded buffer
+    // — at most 512 MiB of fp32 score rows (never fewer than 16 rows) — walked in passes of `slots` flagged queries
+    const int64_t slots = bigk ? 256 : std::min<int64_t>(nqp, std::max<int64_t>(16, (((int64_t)1 << 27) / ldS) / 16 * 16));
     if (ix->qcap < nqp) {
         VRCHK(ix->qbf.alloc((size_t)nqp * dim * 2));
         VRCHK(ix->thr.alloc((size_t)nqp * 4));
@@ -1235,8 +1249,12 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
             HIPCHK(hipStreamSynchronize(s));
         }
     } else {
-        if (ix->fcap < nqp) { VRCHK(ix->flags.alloc((size_t)nqp * 4)); ix->fcap = nqp; }
-        VRCHK(ix->sbuf.reserve((size_t)nqp * ldS * 4));
+        if (ix->fcap < nqp) {
+            VRCHK(ix->flags.alloc((size_t)nqp * 12));
+            VRCHK(ix->flagq.alloc((size_t)(nqp + 256) * dim * 2));     // (+ one tile: the GEMM's last row tile may start anywhere)
+            ix->fcap = nqp;
+        }
+        VRCHK(ix->sbuf.reserve((size_t)slots * ldS * 4));
         for (int64_t q0 = 0; q0 < nq; q0 += qblk) {
             const int nb = (int)std::min<int64_t>(qblk, nq - q0);
             const int64_t nbp = pad256l(nb);
@@ -1244,15 +1262,19 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
             if (prof) HIPCHK(hipEventRecord(ix->prof_ev[0], s));
             // rows >= nb: zeros; also clears the flag counter
             HIPCHK(launch_f32_to_bf16_pad(q32 + (size_t)q0 * dim, ix->qbf.p, (size_t)nb * dim, (size_t)nbp * dim, s,
-                                          ix->cert.as<int>() + 1));
+                                          ix->cert.as<int>() + CERT_FLAG));       // (clears both flag counters)
             if (prof) HIPCHK(hipEventRecord(ix->prof_ev[1], s));
             SearchArgs a{};
             a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
             a.q_bf16 = ix->qbf.p; a.q_f32 = q32 + (size_t)q0 * dim; a.nq = nb; a.k = k;
-            a.eps_rel = ix->eps_rel == -2.f ? search_default_eps_rel(dim) : ix->eps_rel;
+            a.eps_data = ix->eps_rel == -2.f ? 1 : 0;
+            a.eps_rel = a.eps_data ? 0.f : ix->eps_rel;
+            a.acc_rel = search_acc_rel(dim);
             a.dmax = ix->cert.as<float>();
-            a.flag_count = ix->cert.as<int>() + 1; a.flag_list = ix->flags.as<int>();
-            a.stats = ix->cert.as<unsigned>() + 2;
+            a.flag_count = ix->cert.as<int>() + CERT_FLAG; a.flag_list = ix->flags.as<int>();
+            a.flag2_count = ix->cert.as<int>() + CERT_FLAG2; a.flag2_list = ix->flags.as<int>() + ix->fcap;
+            a.flag_tau = ix->flags.as<float>() + 2 * ix->fcap; a.flag_q = ix->flagq.p;
+            a.stats = ix->cert.as<unsigned>() + CERT_STATS;
             if (keys_out) { a.out_keys = ok + (size_t)q0 * k; a.id_offset = id_offset; }
             else { a.out_scores = os + (size_t)q0 * k; a.out_ids = oi + (size_t)q0 * k; }
             a.prof_ev = prof ? ix->prof_ev : nullptr;
@@ -1282,11 +1304,29 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
                 HIPCHK(launch_search(a, s));
             }
             if (prof) HIPCHK(hipEventRecord(ix->prof_ev[4], s));
-            if (a.eps_rel >= 0.f) {
-                // the exact fp32 pass over whatever the merge flagged (nothing, normally: both kernels leave at once)
-                HIPCHK(launch_exact_scores(a.index_f32, a.n_docs, dim, a.q_f32, a.flag_list, a.flag_count, ix->sbuf.as<float>(),
-                                           (size_t)ldS, s));
-                HIPCHK(launch_exact_select(a, ix->sbuf.as<float>(), (size_t)ldS, nb, s));
+            if (a.eps_data || a.eps_rel >= 0.f) {
+                // whatever the merge flagged (nothing, normally: every kernel below leaves at once), `slots` queries per pass:
+                // bf16 score rows of the flagged queries (GEMM over their compacted bf16 rows, row count on the device) ->
+                // every row inside a query's error band re-scored in fp32 (search_band.hip) -> what is left (bands beyond
+                // search_band_max() rows) through the exact fp32 pass over the whole index (search_exact.hip)
+                for (int64_t f0 = 0; f0 < nb; f0 += slots) {
+                    const int ns = (int)std::min<int64_t>(slots, nb - f0);
+                    GemmArgs g{};
+                    g.A = (const char*)ix->flagq.p + (size_t)f0 * dim * 2; g.lda = dim;
+                    g.W = ix->bf16.p; g.ldw = dim; g.M = ns; g.N = (int)pad128l(ix->n); g.K = dim;
+                    g.out = ix->sbuf.p; g.ldo = (int)ldS; g.alpha = 1.0f;
+                    g.m_dev = a.flag_count; g.m_sub = (int)f0;
+                    HIPCHK(launch_gemm(g, EPI_F32, GEMM_VARIANT_256IL, s));
+                    HIPCHK(launch_band_select(a, ix->sbuf.as<float>(), (size_t)ldS, (int)f0, ns, s));
+                }
+                SearchArgs ax = a;
+                ax.flag_count = a.flag2_count; ax.flag_list = a.flag2_list;
+                for (int64_t f0 = 0; f0 < nb; f0 += slots) {
+                    const int ns = (int)std::min<int64_t>(slots, nb - f0);
+                    HIPCHK(launch_exact_scores(a.index_f32, a.n_docs, dim, a.q_f32, ax.flag_list, ax.flag_count, (int)f0, ns,
+                                               ix->sbuf.as<float>(), (size_t)ldS, s));
+                    HIPCHK(launch_exact_select(ax, ix->sbuf.as<float>(), (size_t)ldS, (int)f0, ns, s));
+                }
             }
             if (prof) {
                 HIPCHK(hipEventRecord(ix->prof_ev[5], s));
@@ -1397,6 +1437,14 @@ extern "C" int vr_resize_bicubic(int device_id, const uint8_t* src, int32_t src_
         }
     }
     if (!src_on_device) HIPCHK(hipStreamSynchronize(s));     // the caller may reuse its host buffer
+    return VR_OK;
+}
+
+// ------------------------------------------------------------------------- synthetic input ---
+extern "C" int vr_synth_pages(int device_id, uint8_t* out, int32_t n, int32_t size, int64_t seed, int64_t first, void* stream) {
+    if (!out || n < 0 || size < 64 || size > 4096) return fail(VR_ERR_INVALID, "bad synth_pages arguments");
+    VRCHK(set_dev(device_id));
+    HIPCHK(launch_synth_pages(out, n, size, seed, first, (hipStream_t)stream));
     return VR_OK;
 }
 

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmArgs p) {
     const int g = t / gsz, r = t % gsz;
     const int gm = min(GM, tiles_m - g * GM);         // last group may be shorter
     const int m0 = (g * GM + r % gm) * G256_BM, n0 = (r / gm) * G256_BN;
+    if (p.m_dev && m0 >= p.m_dev[0] - p.m_sub) return;       // row count known on the device only (the search's band pass)
 
     gemm256_acc_t acc;
     gemm256_zero(acc);

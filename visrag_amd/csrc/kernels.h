@@ -30,6 +30,8 @@ struct GemmArgs {
     int raster_gm;                   // 256-tile kernels: m-tiles per raster group (0 = choose by W size)
     int ksplit;                      // 256-tile kernels, EPI_F32 only: split K over ksplit workgroups per tile;
     size_t split_stride;             //   split s writes its partial product to out + s * split_stride (elements)
+    const int* m_dev; int m_sub;     // optional, GEMM_VARIANT_256IL only: rows < *m_dev - m_sub exist (a row count known on the
+                                     // device only: tiles at or past it leave at once — the search's band pass)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // 256x192 tile (gemm192.hip): N % 192 == 0, epilogues BF16 / GELU / F32 / RESID only
@@ -179,7 +181,7 @@ hipError_t launch_pool(const float* h, const int* seq_offsets, int B, int dim, c
                        float eps, float* out, float* tap_hidden, hipStream_t s, int mode = 0);   // mode: VR_POOL_*
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16_pad(const float* in, void* out, size_t n, size_t n_total, hipStream_t s,
-                                  int* zero_word = nullptr);   // + zero tail (+ one int cleared)
+                                  int* zero_word = nullptr);   // + zero tail (+ TWO ints cleared)
 // split x (f32) into hi + lo bf16 parts (x ~= hi + lo to ~16 bits of mantissa)
 hipError_t launch_split_bf16(const float* in, void* hi, void* lo, size_t n, hipStream_t s);
 hipError_t launch_iota_pos(const int* seq_offsets, int B, int* pos, hipStream_t s);
@@ -194,6 +196,9 @@ hipError_t launch_swiglu_split(const float* gu, int T, int ld_gu, int I, int ld_
 hipError_t launch_embed_gather_hp(const int* ids, int T, const void* table_hi, const void* table_lo, int dim, float scale,
                                   float* out, hipStream_t s);
 hipError_t launch_seq_of(const int* seq_offsets, int B, int* seq_of, hipStream_t s);
+
+// ---- synthetic page images (synth.hip; bench / test support): pages first .. first + n - 1 of visrag_amd/synth.py's corpus
+hipError_t launch_synth_pages(uint8_t* out, int n, int size, long long seed, long long first, hipStream_t s);
 
 // ---- PIL-exact bicubic resize (resize.hip) ------------------------------------------------------
 } // namespace vr
@@ -220,10 +225,17 @@ struct SearchArgs {
     unsigned long long* cand_keys;                     // 256-tile sweep scratch [nq_pad256][n_chunks][2][64] or null
     // ---- certification of the candidate selection (search_common.h: certify_tail)
     const float* thr_used;           // thresholds the sweep STARTED from (set by the launcher; null: none)
-    float eps_rel;                   // |bf16-MFMA score - fp32 score| <= eps_rel * |q| * dmax; < 0: no certification
-    const float* dmax;               // device scalar: largest row norm of the index
-    int* flag_count; int* flag_list; // queries whose top-k could not be certified: the exact fp32 pass redoes them
+    float eps_rel;                   // >= 0: |bf16-MFMA score - fp32 score| <= eps_rel * |q| * dmax (the caller's model);
+                                     // < 0: no certification; eps_data set: ignored, the bound is search_common.h's query_eps
+    int eps_data;                    // 1: the default, data-dependent rigorous bound (needs dmax[1] and acc_rel)
+    float acc_rel;                   // its accumulation term: (2 dim + 128) 2^-24
+    const float* dmax;               // device floats: [0] largest row norm |d|, [1] largest bf16 rounding residual |d - bf16(d)|
+    int* flag_count; int* flag_list; // queries whose top-k could not be certified: the band pass (search_band.hip) redoes them
+    float* flag_tau;                 // [slot] the flagged query's tau = s_k - eps (-inf: unknown)
+    void* flag_q;                    // bf16 [slots][dim]: the flagged queries' bf16 rows, compacted (the band pass's GEMM operand)
+    int* flag2_count; int* flag2_list;   // flagged queries whose band holds too many rows: the exact fp32 pass redoes them
     unsigned* stats;                 // [0] certified at once [1] after extended re-scoring [2] flagged [3] uncertified mode
+                                     // [4] candidates gathered a second time [5] of the flagged: redone by the exact fp32 pass
     // ---- packed output (multi-GPU exchange format): key = orderable(score) << 32 | ~(row + id_offset); 0 = none
     unsigned long long* out_keys; int64_t id_offset;   // when set, out_scores / out_ids are not written
     hipEvent_t* prof_ev;             // optional [SEARCH_PROF_EVENTS] stage marks recorded on the launch stream
@@ -254,12 +266,20 @@ hipError_t launch_topk_merge_keys(const unsigned long long* keys, int n_parts, i
 // ---- exact fp32 pass for the flagged queries (search_exact.hip)
 // S[slot][doc] = fp32 dot(query flag_list[slot], row doc) for slot < *flag_count, in the summation order of the
 // re-scoring (search_common.h: dot_lane) — every workgroup leaves at once when nothing is flagged
+// entries [sub, sub + max_slots) of the list are this launch's slots 0.. (a pass over a bounded score buffer)
 hipError_t launch_exact_scores(const float* index_f32, int64_t n_docs, int dim, const float* q_f32, const int* flag_list,
-                               const int* flag_count, float* S, size_t ldS, hipStream_t s);
+                               const int* flag_count, int sub, int max_slots, float* S, size_t ldS, hipStream_t s);
 // top-k of the flagged queries from their exact score rows (radix select + re-score + sort): overwrites their outputs
-hipError_t launch_exact_select(const SearchArgs& a, const float* S, size_t ldS, int max_flagged, hipStream_t s);
-// dmax = max(dmax, |row|) over n rows (vr_index_add)
+// (a.flag_count / a.flag_list: the list the scores were made for)
+hipError_t launch_exact_select(const SearchArgs& a, const float* S, size_t ldS, int sub, int max_slots, hipStream_t s);
+// ---- band pass for the flagged queries (search_band.hip): S[slot][doc] = bf16-MFMA scores of flagged query
+// flag_list[sub + slot] (GEMM over a.flag_q); every row with a score >= its tau re-scored in fp32, top k emitted; a band of
+// more than search_band_max() rows goes on the flag2 list (exact fp32 pass)
+int search_band_max();
+hipError_t launch_band_select(const SearchArgs& a, const float* S, size_t ldS, int sub, int max_slots, hipStream_t s);
+// dmax[0] = max(dmax[0], |row|), dmax[1] = max(dmax[1], |row - bf16(row)|) over n rows (vr_index_add)
 hipError_t launch_row_norm_max(const float* rows, int64_t n, int dim, float* dmax, hipStream_t s);
-float search_default_eps_rel(int dim);
+float search_default_eps_rel(int dim);      // worst-case relative bound (a caller's yardstick; the default bound is data-dependent)
+float search_acc_rel(int dim);
 
 }  // namespace vr

@@ -137,7 +137,7 @@ hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t 
 // n and n_total multiples of 4)
 __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n, size_t n_total,
                                        int* __restrict__ zero_word) {
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;       // (the search's flag counter: saves a memset launch)
+    if (zero_word && blockIdx.x == 0 && threadIdx.x < 2) zero_word[threadIdx.x] = 0;   // (the search's two flag counters: saves a memset launch)
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (; i < n_total; i += stride) {

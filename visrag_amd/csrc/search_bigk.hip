@@ -26,38 +26,22 @@ constexpr int BIGK_MARGIN = 24;
 
 int search_bigk_max() { return BIGK_CAND - BIGK_MARGIN; }
 
-// descending bitonic sort of n (power of two, <= 8192) keys in LDS by the whole workgroup
-__device__ __forceinline__ void block_bitonic_desc(uint64_t* keys, int n, int tid, int nthreads) {
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n; i += nthreads) {
-                const int partner = i ^ j;
-                if (partner > i) {
-                    const uint64_t a = keys[i], b = keys[partner];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[partner] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // exact == 0: S rows are bf16-MFMA scores of queries blockIdx.x; the result is certified like the fused path's
 //   (search_common.h): tau = s_k - eps; if the radix threshold T does not lie below tau, every row with a bf16 score
 //   >= tau is gathered and re-scored instead (up to BIGK_CAND of them), else the query is flagged.
 // exact == 1: S row i holds EXACT fp32 scores of flagged query flag_list[i] (search_exact.hip); plain top-k of it.
 __global__ __launch_bounds__(256) void bigk_select_kernel(SearchArgs p, const float* __restrict__ S, size_t ldS, int kp_want,
-                                                          int exact) {
+                                                          int exact, int sub, int max_slots) {
     __shared__ unsigned hist[2048];
     __shared__ int cand[BIGK_CAND];
     __shared__ uint64_t keys[BIGK_CAND];
     __shared__ unsigned sh_prefix, sh_mask;
     __shared__ int sh_rank, wc[4][2], run[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_slots = exact ? p.flag_count[0] : (int)gridDim.x;       // exact: a fixed grid walks the flag list
+    // exact: a fixed grid walks entries [sub, sub + max_slots) of the flag list
+    const int n_slots = exact ? min(max(p.flag_count[0] - sub, 0), max_slots) : (int)gridDim.x;
     for (int slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
-    const int q = exact ? p.flag_list[slot] : slot;
+    const int q = exact ? p.flag_list[sub + slot] : slot;
     const float* row = S + (size_t)slot * ldS;
     const int n_docs = (int)p.n_docs, k = p.k, dim = p.dim;
     int kp = min(n_docs, kp_want);
@@ -152,15 +136,12 @@ __global__ __launch_bounds__(256) void bigk_select_kernel(SearchArgs p, const fl
     };
     rescore_sort(kp);
     // ---- 4. certification (rows outside the re-scored set have a bf16 score <= T's)
-    if (!exact && p.eps_rel >= 0.f) {
+    if (!exact && (p.eps_data || p.eps_rel >= 0.f)) {
         int what = 0;
+        float tau = -INFINITY;
         if (kp < n_docs) {
-            float qq = 0.f;
-#pragma unroll
-            for (int i = 0; i < MERGE_MAXV; ++i)
-                qq += qv[i][0] * qv[i][0] + qv[i][1] * qv[i][1] + qv[i][2] * qv[i][2] + qv[i][3] * qv[i][3];
-            const float eps = p.eps_rel * sqrtf(wave_sum(qq)) * p.dmax[0];
-            const float tau = key_score(keys[k - 1]) - eps;           // kp >= k here (kp < n_docs => kp = k + margin)
+            const float eps = query_eps(p, qv);
+            tau = key_score(keys[k - 1]) - eps;                       // kp >= k here (kp < n_docs => kp = k + margin)
             if (!(orderable_f32(T) < tau)) {
                 // every row whose bf16 score is >= tau (strictly above the key just below tau's)
                 __syncthreads();
@@ -171,10 +152,9 @@ __global__ __launch_bounds__(256) void bigk_select_kernel(SearchArgs p, const fl
                 else what = 2;
             }
         }
-        if (tid == 0) {
-            if (what == 2 && p.flag_count) { const int pos = atomicAdd(p.flag_count, 1); p.flag_list[pos] = q; }
-            if (p.stats) atomicAdd(&p.stats[what], 1u);
-        }
+        if (tid == 0 && p.stats) atomicAdd(&p.stats[what], 1u);
+        __syncthreads();
+        flag_query(p, q, what == 2, tau, &sh_rank);
     } else if (!exact && tid == 0 && p.stats) {
         atomicAdd(&p.stats[3], 1u);
     }
@@ -188,15 +168,15 @@ hipError_t launch_search_bigk(const SearchArgs& a, const float* S, size_t ldS, i
     (void)q0;
     if (nq_block <= 0) return hipSuccess;
     if (a.k > search_bigk_max() || a.dim % 4 || a.dim > 64 * 4 * MERGE_MAXV) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bigk_select_kernel, dim3(nq_block), dim3(256), 0, s, a, S, ldS, a.k + BIGK_MARGIN, 0);
+    hipLaunchKernelGGL(bigk_select_kernel, dim3(nq_block), dim3(256), 0, s, a, S, ldS, a.k + BIGK_MARGIN, 0, 0, 0);
     return hipGetLastError();
 }
 
 // exact top-k of the flagged queries from their exact score rows (slot i of S = query flag_list[i])
-hipError_t launch_exact_select(const SearchArgs& a, const float* S, size_t ldS, int max_flagged, hipStream_t s) {
-    if (max_flagged <= 0) return hipSuccess;
+hipError_t launch_exact_select(const SearchArgs& a, const float* S, size_t ldS, int sub, int max_slots, hipStream_t s) {
+    if (max_slots <= 0) return hipSuccess;
     if (a.k > BIGK_CAND || a.dim % 4 || a.dim > 64 * 4 * MERGE_MAXV || !a.flag_count || !a.flag_list) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bigk_select_kernel, dim3(max_flagged < 256 ? max_flagged : 256), dim3(256), 0, s, a, S, ldS, a.k, 1);
+    hipLaunchKernelGGL(bigk_select_kernel, dim3(max_slots < 128 ? max_slots : 128), dim3(256), 0, s, a, S, ldS, a.k, 1, sub, max_slots);
     return hipGetLastError();
 }
 

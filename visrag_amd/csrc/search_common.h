@@ -105,10 +105,16 @@ __device__ __forceinline__ void emit_slot(const SearchArgs& p, int q, int slot, 
 
 // ---- certified candidate selection ------------------------------------------------------------
 // The sweeps rank rows by their bf16-MFMA score b(d); the library returns the ranking by the fp32 score
-// s(d).  With q^ = bf16(q), d^ = bf16(d) (round to nearest: relative error <= 2^-9 each) and fp32
-// accumulation of the exact bf16 products over dim terms,
-//     |b(d) - s(d)| <= (2^-8 + 2^-18 + (dim + 64) * 2^-23) * |q| * |d|  =  eps          (Cauchy-Schwarz)
-// (search_default_eps_rel; the caller may set a tighter model with vr_index_set_search_eps).  A row outside
+// s(d).  With q^ = bf16(q) = q + dq, d^ = bf16(d) + ... (round to nearest even: |dx_i| <= 2^-8 |x_i| — bf16 keeps
+// 8 significand bits, its unit roundoff is 2^-8, NOT 2^-9) and fp32 accumulation of the exact bf16 products,
+//     b(d) - s(d) = (fl(q^.d^) - q^.d^) + (dq.d + q.dd + dq.dd) + (q.d - fl(q.d))
+//     |b(d) - s(d)| <= |dq| |d| + |q| |dd| + |dq| |dd| + acc_rel (|q| + |dq|) (|d| + |dd|)              (Cauchy-Schwarz)
+// with acc_rel = (2 dim + 128) 2^-24 covering both fp32 summations in any order (<= 2^-23 per add allows a truncating
+// adder).  The default bound (query_eps, eps_data) uses the MEASURED residual norms: |dq| of the query at hand (computed
+// here), max |d| and max |dd| = max |d - bf16(d)| over the index rows (vr_index_add keeps both) — rigorous for the data
+// that is there, and ~2.5x tighter than the worst case 2^-7 + 2^-16 (search_default_eps_rel), because a random
+// significand sits 0.29 ulp from its rounding on average, not half an ulp.  A caller's own model: eps_rel |q| max|d|
+// (vr_index_set_search_eps).  A row outside
 // the re-scored set R can only belong to the fp32 top-k if s(d) >= s_k (the k-th best fp32 score inside
 // R), i.e. if b(d) >= s_k - eps =: tau.  certify_tail therefore
 //   1. re-scores the bf16 top-KP, takes s_k and tau;
@@ -127,6 +133,65 @@ __device__ __forceinline__ void emit_slot(const SearchArgs& p, int q, int slot, 
 // surv / exact_w: LDS[MERGE_CAP] — what regather() gathered (unsorted) and scratch for its exact keys: when more than 64
 // rows lie inside the error band (a cluster of near-duplicate pages) but no more than MERGE_CAP, ALL of them are re-scored
 // here and the top k taken from that — the exact pass over the whole index is for what exceeds even this.
+
+// bf16 rounding residual of x (exact in fp32: x and bf16(x) agree in their leading bits)
+__device__ __forceinline__ float bf16_resid(float x) { return x - bf2f(f2bf(x)); }
+
+// eps of the certification for the query whose float4 chunks the wave holds in qv (all 64 lanes take part);
+// slack factors cover the fp32 rounding of the norms themselves
+__device__ __forceinline__ float query_eps(const SearchArgs& p, const f32x4 (&qv)[MERGE_MAXV]) {
+    float qq = 0.f, dd = 0.f;
+#pragma unroll
+    for (int i = 0; i < MERGE_MAXV; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = qv[i][r], e = bf16_resid(x);
+            qq = __builtin_fmaf(x, x, qq);
+            dd = __builtin_fmaf(e, e, dd);
+        }
+    const float qn = sqrtf(wave_sum(qq)) * 1.00001f;
+    if (!p.eps_data) return p.eps_rel * qn * p.dmax[0];
+    const float dq = sqrtf(wave_sum(dd)) * 1.00001f;
+    const float dn = p.dmax[0], dr = p.dmax[1];
+    return (dq * dn + qn * dr + dq * dr + p.acc_rel * (qn + dq) * (dn + dr)) * 1.00001f;
+}
+
+// a query that could not be certified goes on the flag list with its tau and its bf16 row (the band pass's GEMM operand);
+// called by the whole workgroup with `flagged` workgroup-uniform; sh_pos: LDS scratch
+__device__ __forceinline__ void flag_query(const SearchArgs& p, int q, bool flagged, float tau, int* sh_pos) {
+    if (!flagged || !p.flag_count) return;
+    if (threadIdx.x == 0) {
+        const int pos = atomicAdd(p.flag_count, 1);
+        p.flag_list[pos] = q;
+        if (p.flag_tau) p.flag_tau[pos] = tau;
+        *sh_pos = pos;
+    }
+    __syncthreads();
+    if (p.flag_q) {
+        const int pos = *sh_pos;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>((const char*)p.q_bf16 + (size_t)q * p.dim * 2);
+        uint32_t* dst = reinterpret_cast<uint32_t*>((char*)p.flag_q + (size_t)pos * p.dim * 2);
+        for (int c = threadIdx.x; c < p.dim / 2; c += blockDim.x) dst[c] = src[c];
+    }
+}
+
+// descending bitonic sort of n (power of two) keys in LDS by the whole workgroup
+__device__ __forceinline__ void block_bitonic_desc(uint64_t* keys, int n, int tid, int nthreads) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n; i += nthreads) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const uint64_t a = keys[i], b = keys[partner];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int KP, typename Regather>
 __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
                                              float coverB, float dropB, float* sh_tau, int* sh_x, Regather regather,
@@ -148,15 +213,11 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
     __syncthreads();
     for (int c = wave; c < KP; c += 4) rescore(c);
     __syncthreads();
-    const bool certify = p.eps_rel >= 0.f;
+    const bool certify = p.eps_data || p.eps_rel >= 0.f;
     if (wave == 0) {
         float tau = -INFINITY;
         if (certify) {
-            float qq = 0.f;
-#pragma unroll
-            for (int i = 0; i < MERGE_MAXV; ++i)
-                qq += qv[i][0] * qv[i][0] + qv[i][1] * qv[i][1] + qv[i][2] * qv[i][2] + qv[i][3] * qv[i][3];
-            const float eps = p.eps_rel * sqrtf(wave_sum(qq)) * p.dmax[0];
+            const float eps = query_eps(p, qv);
             const uint64_t kth = shfl_u64(wave_sort_desc(exact_s[lane]), p.k - 1);
             if (kth != KEY_NONE) tau = key_score(kth) - eps;
         }
@@ -205,16 +266,12 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
         if (lane < p.k) emit_slot(p, q, lane, ex);
         if (lane == 0) {
             int what = 3;
-            if (certify) {
-                what = (below(coverB, tau) && below(dropB, tau)) ? ((x || again) ? 1 : 0) : 2;
-                if (what == 2 && p.flag_count) {
-                    const int pos = atomicAdd(p.flag_count, 1);
-                    p.flag_list[pos] = q;
-                }
-            }
+            if (certify) what = (below(coverB, tau) && below(dropB, tau)) ? ((x || again) ? 1 : 0) : 2;
             if (p.stats) atomicAdd(&p.stats[what], 1u);
         }
     }
+    // (coverB / dropB / tau / x are workgroup-uniform: every thread evaluates the same predicate)
+    flag_query(p, q, certify && !(below(coverB, tau) && below(dropB, tau)), tau, sh_x);
 }
 
 }  // namespace vr

@@ -266,14 +266,26 @@ class HipIndex:
         return keys
 
     def set_search_eps(self, eps_rel: Optional[float]) -> None:
-        """Error model of the top-k certification: None = the rigorous default, < 0 = certification off."""
+        """Error model of the top-k certification: None = the rigorous data-dependent default, >= 0 = eps_rel * |q| * max|d|,
+        < 0 = certification off."""
         _lib.check(self.lib.vr_index_set_search_eps(self._h, float("nan") if eps_rel is None else float(eps_rel)))
 
     def search_stats(self, reset: bool = False) -> Dict[str, int]:
-        out = (C.c_int64 * 5)()
+        """Queries since the last reset by outcome: certified from the sweep's candidates at once / after re-scoring more of
+        them; `flagged` = redone behind the sweep, of which `band_pass` by re-scoring every row inside the error band and
+        `exact_pass` by the fp32 pass over the whole index; `uncertified` = searched with certification off."""
+        out = (C.c_int64 * 6)()
         _lib.check(self.lib.vr_index_search_stats(self._h, out, 1 if reset else 0))
-        return {"certified": int(out[0]), "certified_extended": int(out[1]), "exact_pass": int(out[2]),
+        return {"certified": int(out[0]), "certified_extended": int(out[1]), "flagged": int(out[2]),
+                "band_pass": int(out[2]) - int(out[5]), "exact_pass": int(out[5]),
                 "uncertified": int(out[3]), "regathered": int(out[4])}
+
+    def error_model(self) -> Dict[str, float]:
+        """What the default certification bound is made of (include/visrag_hip.h: vr_index_set_search_eps)."""
+        out = (C.c_float * 4)()
+        _lib.check(self.lib.vr_index_error_model(self._h, out))
+        return {"max_row_norm": float(out[0]), "max_row_bf16_residual": float(out[1]), "acc_rel": float(out[2]),
+                "worst_case_eps_rel": float(out[3])}
 
     SEARCH_STAGES = ("convert", "thresholds", "sweep", "merge", "exact_pass")
 

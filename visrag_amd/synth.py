@@ -201,3 +201,19 @@ def synth_queries(n: int, seed: int = 0, min_words: int = 4, max_words: int = 12
         k = int(rng.integers(min_words, max_words + 1))
         out.append(" ".join(_WORDS[int(j)] for j in rng.integers(0, len(_WORDS), size=k)))
     return out
+
+
+def synth_pages_gpu(n: int, size: int = 448, seed: int = 0, first: int = 0, device: int = 0, out=None):
+    """The same pages as `synth_pages(n, size, seed, first)`, bit for bit, produced on the GPU (vr_synth_pages):
+    uint8 cuda tensor [n, size, size, 3].  100 000 distinct pages for BASELINE config 3 take seconds instead of the
+    host generator's half hour."""
+    import ctypes as C
+
+    from . import _lib
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((n, size, size, 3), dtype=torch.uint8, device=f"cuda:{device}")
+    assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= n * size * size * 3
+    _lib.check(lib.vr_synth_pages(int(device), C.c_void_p(out.data_ptr()), int(n), int(size), int(seed), int(first),
+                                  C.c_void_p(int(torch.cuda.current_stream(int(device)).cuda_stream))), "vr_synth_pages")
+    return out[:n]
