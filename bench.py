@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--index-rows", type=int, default=100_000)
+    ap.add_argument("--corpus-pages", type=int, default=100_000,
+                    help="DISTINCT synthetic pages embedded by the model into the retrieval index, whole job (BASELINE configs[2]: "
+                         "100k, ~2.5 minutes on one GPU); 0 = skip, search the i.i.d. filler index only")
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--search-steps", type=int, default=20)
@@ -164,24 +167,33 @@ def main():
                      "ms_per_step": round(dp / (2 * args.steps) * 1e3, 3)}
         enc2.close()
 
-    # ---- retrieval: fill the shard to index_rows/world rows with synthetic unit-norm embeddings,
-    #      encode the text queries with the model, then time sharded search
-    # the timed steps walked the pool of 2 x batch distinct pages several times: keep ONE embedding of each page in the
-    # retrieval index (copies of a page are exact ties — a property of this loop, not of a corpus)
-    index.reset()
-    for it, px in batches:
-        enc.encode_items(it, device_slices=px, out=out)
-        index.add(out)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    have = len(index)
-    filler = torch.randn((rows_local - min(have, rows_local), cfg.hidden_size), generator=g, device=dev)
-    filler = filler / filler.norm(dim=1, keepdim=True)
-    if have > rows_local:
-        index.reset()
-        filler = torch.randn((rows_local, cfg.hidden_size), generator=g, device=dev)
-        filler = filler / filler.norm(dim=1, keepdim=True)
-    index.add(filler)
-    del filler
+    # ---- retrieval half of the metric (BASELINE configs[2] / [3]) ------------------------------------------------
+    # (1) "model" index — configs[2] AS WORDED: this rank's share of `--corpus-pages` DISTINCT synthetic pages (generated on
+    #     the GPU, visrag_amd/synth.py) is embedded by the model and appended to the HBM-resident index, the text queries are
+    #     encoded by the model, and the search runs over THOSE embeddings; (2) "filler": i.i.d. Gaussian unit rows — what
+    #     rounds 1-3 timed, kept beside it; (3) "templated": 100 families x 1000 near-duplicate pages laid out contiguously
+    #     (a deck embedded page after page), built by perturbing model embeddings: the certification's worst case.
+    E = cfg.hidden_size
+    rows_local = (args.index_rows + world - 1) // world
+    corpus_local = (min(args.corpus_pages, args.index_rows) + world - 1) // world if args.corpus_pages > 0 else 0
+    emb_m = None
+    corpus_embed = None
+    if corpus_local > 0:
+        from visrag_amd.synth import synth_pages_gpu
+        emb_m = torch.empty((corpus_local, E), dtype=torch.float32, device=dev)
+        pxbuf = torch.empty((B, 448, 448, 3), dtype=torch.uint8, device=dev)
+        tmpl = [items[0]] * B                                      # every 448 x 448 page has the same token layout
+        barrier()
+        tc0 = time.perf_counter()
+        for lo in range(0, corpus_local, B):
+            nb = min(B, corpus_local - lo)
+            synth_pages_gpu(nb, size=448, seed=0, first=1_000_000 + rank * corpus_local + lo, device=local_rank, out=pxbuf)
+            enc.encode_items(tmpl[:nb], device_slices=[pxbuf[i] for i in range(nb)], out=emb_m[lo:lo + nb])
+        barrier()
+        dc = max_over_ranks(time.perf_counter() - tc0)
+        corpus_embed = {"pages": corpus_local * world, "pages_per_sec": round(corpus_local * world / dc, 1), "seconds": round(dc, 1),
+                        "what": "distinct synthetic pages generated on the GPU -> vr_encode -> fp32 rows kept in HBM (single stream)"}
+        log(f"[rank {rank}] corpus of {corpus_local} pages embedded in {dc:.1f}s")
     qtexts = [QUERY_PREFIX + q for q in synth_queries(args.queries, seed=0)]
     qitems = prepare_batch(qtexts, [None] * len(qtexts), tok, cfg, 512)
     barrier()
@@ -192,15 +204,138 @@ def main():
     Q = torch.cat(qreps)
     barrier()
     q_encode_s = time.perf_counter() - tq0
-    for _ in range(3):
-        sc, ids = sharded_search(index, Q, args.topk, id_offset=rank * rows_local)
-    barrier()
-    ts0 = time.perf_counter()
-    for _ in range(args.search_steps):
-        sc, ids = sharded_search(index, Q, args.topk, id_offset=rank * rows_local)
-    barrier()
-    ds = max_over_ranks(time.perf_counter() - ts0)
-    search_qps = args.queries * args.search_steps / ds
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def ids_vs_fp64(rows: torch.Tensor, ids: torch.Tensor, sc: torch.Tensor):
+        """the local search's ids against an fp64 brute force over the same fp32 rows (the checker: torch fp64 matmul)"""
+        ref = Q.double() @ rows.double().T
+        rv, ri = torch.topk(ref, args.topk, dim=1)
+        got = torch.gather(ref, 1, ids)
+        differ = ids != ri
+        gap = float((rv - got).abs()[differ].max()) if bool(differ.any()) else 0.0
+        err = float((got - sc.double()).abs().max())
+        return {"queries_with_identical_ids": int((~differ.any(dim=1)).sum()), "queries": int(ids.shape[0]),
+                "max_fp64_score_gap_where_ids_differ": gap, "max_returned_score_error": err,
+                "ok": bool(gap < 3e-7 and err < 2e-6),
+                "what": "ids differ from the fp64 ranking only where two fp64 scores are closer than fp32 summation noise (3e-7)"}
+
+    def search_bench(index, rows, kind, check):
+        for _ in range(3):
+            sc, ids = sharded_search(index, Q, args.topk, id_offset=rank * rows_local)
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(args.search_steps):
+            sc, ids = sharded_search(index, Q, args.topk, id_offset=rank * rows_local)
+        barrier()
+        ds = max_over_ranks(time.perf_counter() - ts0)
+        e0.record()
+        for _ in range(args.search_steps):
+            lsc, lids = index.search(Q, args.topk)
+        e1.record()
+        torch.cuda.synchronize()
+        sweep_ms = e0.elapsed_time(e1) / args.search_steps
+        flops = 2.0 * args.queries * len(index) * E
+        index.search_stats(reset=True)
+        index.set_search_profile(True)
+        for _ in range(args.search_steps):
+            index.search(Q, args.topk)
+        stages = index.get_search_profile()
+        index.set_search_profile(False)
+        cert = index.search_stats()
+        n_cert = max(1, cert["certified"] + cert["certified_extended"] + cert["flagged"] + cert["uncertified"])
+        for _ in range(3):
+            index.search(Q[:1], args.topk)
+        e0.record()
+        for _ in range(20):
+            index.search(Q[:1], args.topk)
+        e1.record()
+        torch.cuda.synchronize()
+        one_ms = e0.elapsed_time(e1) / 20
+        d = {"index_kind": kind, "index_rows": len(index) * world, "rows_per_gpu": len(index), "queries": args.queries, "k": args.topk,
+             "queries_per_sec": round(args.queries * args.search_steps / ds, 1),
+             "ms_per_search": round(ds / args.search_steps * 1e3, 3),
+             "local_sweep_ms": round(sweep_ms, 3),
+             "local_sweep_tflops": round(flops / (sweep_ms * 1e-3) / 1e12, 1),
+             "local_sweep_frac_of_mfma_peak": round(flops / (sweep_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+             "index_GBps": round(len(index) * E * 2 / (sweep_ms * 1e-3) / 1e9, 1),
+             "stages_ms": {k: round(v, 4) for k, v in stages.items() if k != "calls"},
+             "sweep_kernel_tflops": round(flops / max(stages["sweep"], 1e-9) / 1e9, 1),
+             "error_model": {k: float(f"{v:.4g}") for k, v in index.error_model().items()},
+             "certification": {"certified_at_once": round(cert["certified"] / n_cert, 4),
+                               "certified_after_extended_rescoring": round(cert["certified_extended"] / n_cert, 4),
+                               "band_pass": round(cert["band_pass"] / n_cert, 4),
+                               "exact_fp32_pass": round(cert["exact_pass"] / n_cert, 4),
+                               "gathered_twice": round(cert["regathered"] / n_cert, 4),
+                               "what": "fraction of queries; the ids returned are the fp32 ranking's (rigorous bf16 error bound "
+                                       "from the data's measured rounding residuals, visrag_hip.h: vr_index_set_search_eps); "
+                                       "band_pass / exact_fp32_pass = redone behind the sweep (search_band.hip / search_exact.hip)"},
+             "single_query": {"ms": round(one_ms, 4), "bound": "hbm",
+                              "index_GBps": round(len(index) * E * 2 / (one_ms * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": round(len(index) * E * 2 / (one_ms * 1e-3) / 1e9 / 8000.0, 4)}}
+        if check and rows is not None:
+            d["ids_vs_fp64"] = ids_vs_fp64(rows, lids, lsc)
+        return d, ds
+
+    searches = {}
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    if emb_m is not None:
+        index.reset()
+        index_m = HipIndex(E, corpus_local, device=local_rank)
+        index_m.add(emb_m)
+        searches["model"], ds_main = search_bench(index_m, emb_m, "model", True)
+        # what the corpus looks like to the search (the filler's page-page cosines are ~0 +- 0.02)
+        sub = emb_m[:: max(1, corpus_local // 2000)][:2000]
+        cc = (sub @ sub.T)
+        iu = torch.triu_indices(cc.shape[0], cc.shape[0], 1, device=dev)
+        pc = cc[iu[0], iu[1]]
+        qs = (Q @ sub.T)
+        searches["model"]["embedding_stats"] = {
+            "page_page_cosine": {"median": round(float(pc.median()), 4), "p99": round(float(pc.quantile(0.99)), 4), "max": round(float(pc.max()), 4)},
+            "query_page_score": {"mean": round(float(qs.mean()), 4), "std_over_pages": round(float(qs.std(dim=1).mean()), 5)}}
+        index_m.close()
+    filler = torch.randn((rows_local, E), generator=g, device=dev)
+    filler = filler / filler.norm(dim=1, keepdim=True)
+    index.reset()
+    index.add(filler)
+    searches["filler"], ds_f = search_bench(index, filler, "filler", True)
+    if emb_m is None:
+        ds_main = ds_f
+    # the exact fp32 pass and the band pass, priced: 8 / 256 queries forced through them (an error model nothing satisfies
+    # flags every query with the whole index as its band -> exact pass; the templated corpus below exercises the band pass)
+    def timed(nq_, reps=5):
+        index.search(Q[:nq_], args.topk)
+        e0.record()
+        for _ in range(reps):
+            index.search(Q[:nq_], args.topk)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    base8 = timed(8)
+    index.set_search_eps(100.0)
+    forced8 = timed(8)
+    index.set_search_eps(None)
+    searches["filler"]["exact_pass_ms_per_8q"] = round(forced8 - base8, 4)
+    del filler
+    templated = None
+    if emb_m is not None and world == 1 and corpus_local >= 100 and not args.no_extras:
+        n_fam = 100
+        per = rows_local // n_fam
+        t_f = torch.logspace(np.log10(0.176), np.log10(0.0316), n_fam, device=dev)       # pairwise cosine 0.97 .. 0.999 inside a family
+        centers = emb_m[torch.linspace(0, corpus_local - 1, n_fam, device=dev).long()]
+        rows_t = torch.empty((n_fam * per, E), dtype=torch.float32, device=dev)
+        for f in range(n_fam):
+            noise = torch.randn((per, E), generator=g, device=dev) / (E ** 0.5)
+            r_ = centers[f][None, :] + t_f[f] * noise
+            rows_t[f * per:(f + 1) * per] = r_ / r_.norm(dim=1, keepdim=True)
+        index.reset()
+        index.add(rows_t)
+        templated, _ = search_bench(index, rows_t, "templated", True)
+        templated["what"] = (f"{n_fam} families x {per} pages, contiguous, pairwise cosine 0.97 .. 0.999 inside a family (model embeddings "
+                             "perturbed): the pre-pass threshold and the half-lists of a family's chunk sit inside the error band")
+        templated["vs_filler_time"] = round(templated["local_sweep_ms"] / searches["filler"]["local_sweep_ms"], 2)
+        del rows_t
+    main_kind = "model" if emb_m is not None else "filler"
+    srch = searches[main_kind]
+    search_qps = srch["queries_per_sec"]
     # the exchange step alone: ONE all-gather of the packed [nq, k] keys (8 B each) per search
     gather_us = None
     if world > 1:
@@ -216,34 +351,6 @@ def main():
             dist.all_gather_into_tensor(buf, mine)
         barrier()
         gather_us = max_over_ranks(time.perf_counter() - tg0) / 20 * 1e6
-    # event-timed local sweep (kernel time only, for the search roofline)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.search_steps):
-        index.search(Q, args.topk)
-    e1.record()
-    torch.cuda.synchronize()
-    sweep_ms = e0.elapsed_time(e1) / args.search_steps
-    search_flops = 2.0 * args.queries * len(index) * cfg.hidden_size
-    # per-stage split of the local search (HIP events inside vr_index_search; a separate pass: every profiled call ends
-    # with an event synchronisation) and what the top-k certification did with the queries
-    index.search_stats(reset=True)
-    index.set_search_profile(True)
-    for _ in range(args.search_steps):
-        index.search(Q, args.topk)
-    search_stages = index.get_search_profile()
-    index.set_search_profile(False)
-    cert = index.search_stats()
-    n_cert = max(1, cert["certified"] + cert["certified_extended"] + cert["exact_pass"] + cert["uncertified"])
-    # the HBM-bound regime: ONE query against the local shard, bytes = bf16 index size
-    for _ in range(3):
-        index.search(Q[:1], args.topk)
-    e0.record()
-    for _ in range(20):
-        index.search(Q[:1], args.topk)
-    e1.record()
-    torch.cuda.synchronize()
-    one_ms = e0.elapsed_time(e1) / 20
 
     if rank != 0:
         if world > 1:
@@ -280,6 +387,7 @@ def main():
         pass
     phases = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()}
+    # (dec_* = the decoder phase split by events BETWEEN its kernels: shares; "decoder" is the undisturbed total)
     f_page = cfg.flops_page(1024, len(items[0].input_ids))
     result = {
         "metric": "page-images embedded/sec (VisRAG-Ret encode, 448x448, bf16 MFMA) "
@@ -295,28 +403,16 @@ def main():
         "model_tflops": round(pages_per_s * f_page / 1e12 / world, 1),
         "model_frac_of_mfma_peak": round(pages_per_s * f_page / 1e12 / world / PEAK_BF16_TFLOPS, 4),
         "queries_per_sec": round(search_qps, 1),
-        "search": {"index_rows": args.index_rows, "rows_per_gpu": len(index), "queries": args.queries,
-                   "k": args.topk, "ms_per_search": round(ds / args.search_steps * 1e3, 3),
-                   "exchange": None if world == 1 else {
-                       "collective": "all_gather_into_tensor of the packed [nq, k] 64-bit keys, one per search",
-                       "backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                       "bytes_per_rank": args.queries * args.topk * 8, "all_gather_us": round(gather_us, 1)},
-                   "local_sweep_ms": round(sweep_ms, 3),
-                   "local_sweep_tflops": round(search_flops / (sweep_ms * 1e-3) / 1e12, 1),
-                   "local_sweep_frac_of_mfma_peak": round(search_flops / (sweep_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                   "index_GBps": round(len(index) * cfg.hidden_size * 2 / (sweep_ms * 1e-3) / 1e9, 1),
-                   "stages_ms": {k: round(v, 4) for k, v in search_stages.items() if k != "calls"},
-                   "sweep_kernel_tflops": round(search_flops / max(search_stages["sweep"], 1e-9) / 1e9, 1),
-                   "certification": {"certified_at_once": round(cert["certified"] / n_cert, 4),
-                                     "certified_after_extended_rescoring": round(cert["certified_extended"] / n_cert, 4),
-                                     "exact_fp32_pass": round(cert["exact_pass"] / n_cert, 4),
-                                     "gathered_twice": round(cert["regathered"] / n_cert, 4),
-                                     "what": "fraction of queries; the ids returned are the fp32 ranking's (rigorous bf16 "
-                                             "error bound, visrag_hip.h: vr_index_search)"},
-                   "query_encode_per_sec": round(args.queries / q_encode_s, 1),
-                   "single_query": {"ms": round(one_ms, 4), "bound": "hbm",
-                                    "index_GBps": round(len(index) * cfg.hidden_size * 2 / (one_ms * 1e-3) / 1e9, 1),
-                                    "frac_of_hbm_peak": round(len(index) * cfg.hidden_size * 2 / (one_ms * 1e-3) / 1e9 / 8000.0, 4)}},
+        # the retrieval half on the index BASELINE configs[2] words: model-embedded pages, model-encoded queries
+        # (index_kind "filler" only when the corpus embed was skipped with --corpus-pages 0)
+        "search": dict(srch, exchange=None if world == 1 else {
+                           "collective": "all_gather_into_tensor of the packed [nq, k] 64-bit keys, one per search",
+                           "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "bytes_per_rank": args.queries * args.topk * 8, "all_gather_us": round(gather_us, 1)},
+                       query_encode_per_sec=round(args.queries / q_encode_s, 1)),
+        "search_filler": searches["filler"] if main_kind != "filler" else None,
+        "search_templated": templated,
+        "corpus_embed": corpus_embed,
         "roofline": roofline,
         "phases": phases,
         "pipelined": pipelined,
@@ -333,7 +429,7 @@ def main():
             model.set_pipeline(2)
             # (a) PIL pages in -> pickle shards out through distributed_parallel_embedding_inference: host
             #     prompt/tokenise, H2D of the pixels, GPU resize (identity for 448x448), encode, D2H, pickle
-            n_pil = 32 * B                                    # (8 batches: the first and the last one's flush are a tenth of the run)
+            n_pil = 64 * B                                    # (64 batches: pipeline fill and the final flush are ~3 % of the run)
             pil_pages = [Image.fromarray(pages[i % pool]) for i in range(n_pil)]
             corpus = [{"id": str(i), "text": "", "image": im} for i, im in enumerate(pil_pages)]
             with tempfile.TemporaryDirectory() as td:

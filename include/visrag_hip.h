@@ -68,7 +68,11 @@ typedef struct vr_config {
     int32_t max_seqs;          /* workspace: sequences per vr_encode call */
     int32_t text_split_precision; /* 1: token-only batches (queries, text passages) run the decoder on hi + lo bf16
                                    * splits of activations and fp32 source weights with fp32 glue (fp32-class accuracy:
-                                   * the 1e-3 score bar for ~20-token queries); 0: the bf16 path for everything */
+                                   * the 1e-3 score bar for ~20-token queries); 0: the bf16 path for everything;
+                                   * N > 1: only token-only batches whose longest sequence has <= N tokens (512 = the
+                                   * reference's query length): longer text passages stay on the bf16 MFMA attention path.
+                                   * The same text item is therefore embedded at fp32-class precision in a token-only batch
+                                   * and at bf16 precision (inside 1e-3) in a batch that also holds an image. */
 } vr_config_t;
 
 /* ---- library ------------------------------------------------------------------------ */
@@ -147,7 +151,14 @@ int vr_model_set_taps(vr_model_t m, int32_t enable);
 #define VR_PROF_VIT_FC2 4    /* gemm_bf16_kernel<EPI_RESID> : MLP fc2 + residual        */
 #define VR_PROF_RESAMPLER 5  /* whole resampler phase (several kernels)                 */
 #define VR_PROF_DECODER 6    /* whole 40-layer decoder phase (several kernels)          */
-#define VR_PROF_CLASSES 7
+/* the decoder phase again, split (events between its kernels: read these for shares, VR_PROF_DECODER for the total) */
+#define VR_PROF_DEC_QKV 7    /* q|k|v projection + RoPE epilogue                        */
+#define VR_PROF_DEC_ATTN 8   /* causal attention over the packed sequences              */
+#define VR_PROF_DEC_O 9      /* o projection (split-K planes or residual epilogue)      */
+#define VR_PROF_DEC_GU 10    /* gate|up projection + SwiGLU epilogue                    */
+#define VR_PROF_DEC_DOWN 11  /* down projection                                         */
+#define VR_PROF_DEC_NORM 12  /* RMSNorm passes (incl. the split-K accumulate)           */
+#define VR_PROF_CLASSES 13
 int vr_model_set_profile(vr_model_t m, int32_t enable);
 int vr_model_get_profile(vr_model_t m, int32_t cls, double* total_ms, int64_t* launches,
                          double* total_flops);

@@ -322,3 +322,236 @@ def test_evisrag_token_loop_and_placeholder_expansion():
         assert LLM._continue(s, 100, 40, 50, sp, {100}, pipelined) == [100] and s.issued == 0
         s = Stub()
         assert LLM._continue(s, 100, 40, 1, sp, set(), pipelined) == [100] and s.issued == 0
+
+
+RETRIEVE_WORKER = r'''
+import io, os, sys, types
+sys.path.insert(0, os.environ["VR_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from oracle import visrag_ret_oracle as O
+from visrag_amd.retriever import distributed_parallel_retrieve, merge_keys_host, pack_keys_host
+from visrag_amd.utils import save_as_trec
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["VR_PORT"],
+                        rank=int(os.environ["VR_RANK"]), world_size=2)
+rank = dist.get_rank()
+calls = {"n": 0}
+real_gather = dist.all_gather_into_tensor
+def counting_gather(*a, **k):
+    calls["n"] += 1
+    return real_gather(*a, **k)
+dist.all_gather_into_tensor = counting_gather
+
+
+class HostIndex:                      # CPU stand-in for HipIndex: the oracle's matmul + top-k (fixed tie rule)
+    def __init__(self, dim, capacity, device=0):
+        self.rows = np.zeros((0, dim), np.float32)
+    def add(self, reps):
+        self.rows = np.concatenate([self.rows, np.asarray(reps, np.float32)])
+    def __len__(self):
+        return len(self.rows)
+    def _search(self, q, k):
+        q = q.numpy() if isinstance(q, torch.Tensor) else q
+        kk = min(k, len(self.rows))
+        s, i = O.search_topk(q, self.rows, kk)
+        pad = k - kk
+        return (np.pad(s, ((0, 0), (0, pad)), constant_values=-np.inf), np.pad(i, ((0, 0), (0, pad)), constant_values=-1))
+    def search(self, q, k):
+        return self._search(q, k)
+    def search_keys(self, q, k, id_offset=0):
+        s, i = self._search(q, k)
+        return torch.from_numpy(pack_keys_host(s, i, id_offset))
+    def close(self):
+        pass
+
+
+def merge_keys(keys):
+    s, i = merge_keys_host(keys.numpy(), keys.shape[2])
+    return torch.from_numpy(s), torch.from_numpy(i)
+
+
+def trec(res, path):
+    save_as_trec(res, path)
+    return open(path, "rb").read()
+
+
+out = os.environ["VR_OUT"]
+args = types.SimpleNamespace(output_dir=out, process_index=rank)
+for k in (3, 7):
+    for gt in (False, True):
+        ref = distributed_parallel_retrieve(args, k, global_topk=gt, sharded=False, index_factory=HostIndex)
+        n0 = calls["n"]
+        got = distributed_parallel_retrieve(args, k, global_topk=gt, sharded=True, index_factory=HostIndex, merge_keys=merge_keys)
+        assert calls["n"] == n0 + 1, calls                    # ONE data-path collective
+        assert list(got.keys()) == list(ref.keys()) and got == ref, (rank, k, gt)
+        a = trec(ref, os.path.join(out, f"ref.{rank}.{k}.{gt}.trec")); b = trec(got, os.path.join(out, f"got.{rank}.{k}.{gt}.trec"))
+        assert a == b and len(a) > 0, (rank, k, gt)
+# the switches: args.sharded_corpus / VISRAG_SHARDED_RETRIEVE route the unchanged call into the sharded form
+n0 = calls["n"]
+args.sharded_corpus = True
+got = distributed_parallel_retrieve(args, 5, index_factory=HostIndex, merge_keys=merge_keys)
+assert calls["n"] == n0 + 1
+del args.sharded_corpus
+os.environ["VISRAG_SHARDED_RETRIEVE"] = "1"
+got2 = distributed_parallel_retrieve(args, 5, index_factory=HostIndex, merge_keys=merge_keys)
+assert calls["n"] == n0 + 2 and got2 == got
+os.environ["VISRAG_SHARDED_RETRIEVE"] = "0"
+got3 = distributed_parallel_retrieve(args, 5, index_factory=HostIndex)
+assert calls["n"] == n0 + 2 and got3 == got
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_corpus_sharded_retrieve_behind_the_kept_api_world2_gloo(tmp_path):
+    """Row g: `distributed_parallel_retrieve` in its corpus-sharded form (rank r loads only the shards rank r wrote, all
+    queries searched everywhere, ONE all-gather of packed keys, each rank returns ITS queries) == the replicated form of
+    the reference, dict for dict and TREC file byte for byte — union-of-per-file-top-k and global top-k, a rank with two
+    split files and one with a file shorter than k, exact ties across ranks."""
+    import socket
+    from visrag_amd.utils import shard_name, write_shard
+    rng = np.random.default_rng(7)
+    dim = 16
+    C = rng.standard_normal((260, dim)).astype(np.float32)
+    C[250] = C[20]; C[130] = C[20]                         # exact ties across files and ranks
+    Q = rng.standard_normal((9, dim)).astype(np.float32)
+    out = tmp_path / "emb"; out.mkdir()
+    docs = [f"doc{i}" for i in range(260)]
+    write_shard(str(out / shard_name("corpus", 0, 0, 120)), C[:120], docs[:120])
+    write_shard(str(out / shard_name("corpus", 0, 120, 255)), C[120:255], docs[120:255])
+    write_shard(str(out / shard_name("corpus", 1)), C[255:260], docs[255:260])       # 5 rows: shorter than k = 7
+    write_shard(str(out / shard_name("query", 0)), Q[:5], [f"q{i}" for i in range(5)])
+    write_shard(str(out / shard_name("query", 1)), Q[5:], [f"q{i}" for i in range(5, 9)])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(RETRIEVE_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, VR_ROOT=ROOT, VR_PORT=str(port), VR_RANK=str(r), VR_OUT=str(out))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_sharded_search_accepts_the_round2_hooks():
+    """ADVICE round 3: the `local_search` / `merge` kwargs and pack_topk / unpack_topk of round 2 still work (deprecated)."""
+    import warnings
+    import torch
+    from oracle import visrag_ret_oracle as O
+    from visrag_amd.retriever import pack_keys_host, pack_topk, sharded_search, unpack_topk
+    rng = np.random.default_rng(3)
+    C = rng.standard_normal((50, 8)).astype(np.float32); Q = rng.standard_normal((4, 8)).astype(np.float32)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sc, ids = sharded_search(None, torch.from_numpy(Q), 5, id_offset=100,
+                                 local_search=lambda q, k: O.search_topk(q.numpy(), C, k),
+                                 merge=lambda s, i: (s[0], i[0]))
+        assert any(issubclass(x.category, DeprecationWarning) for x in w)
+        rs, ri = O.search_topk(Q, C, 5)
+        assert np.array_equal(ids.numpy(), ri + 100) and np.array_equal(sc.numpy(), rs)
+        p = pack_topk(torch.from_numpy(rs), torch.from_numpy(ri), 100)
+        assert np.array_equal(p.numpy(), pack_keys_host(rs, ri, 100))
+        us, ui = unpack_topk(p)
+        assert np.array_equal(us.numpy(), rs) and np.array_equal(ui.numpy(), ri + 100)
+
+
+def test_sentencepiece_tokenizer_wrapper(tmp_path):
+    """`SentencePieceTokenizer`: the attribute set the path reads from the reference's LlamaTokenizerWrapper
+    (modeling_minicpmv.py:404-438) over a real sentencepiece model — trained here, llama-style (identity normaliser,
+    dummy prefix, byte fallback, the MiniCPM-V markers as user-defined symbols): marker ids, `<unk>` placeholders,
+    per-piece encoding with the legacy prefix, and the image_bound the host side derives from those ids."""
+    import random
+    import sentencepiece as spm
+    from visrag_amd.config import tiny_config
+    from visrag_amd.preprocess import prepare_batch
+    from visrag_amd.synth import synth_pages
+    from visrag_amd.tokenizer import SentencePieceTokenizer
+    from PIL import Image
+    words = ("revenue table chart figure growth annual report market share total net income page section summary results "
+             "Represent this query for retrieving relevant documents").split()
+    random.seed(0)
+    sents = [" ".join(random.choice(words) for _ in range(random.randint(3, 12))) for _ in range(1500)]
+    prefix = str(tmp_path / "tokenizer")
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(sents), model_prefix=prefix, vocab_size=400, model_type="bpe",
+                                   unk_id=0, bos_id=1, eos_id=2, pad_id=-1, byte_fallback=True, character_coverage=1.0,
+                                   normalization_rule_name="identity", remove_extra_whitespaces=False, add_dummy_prefix=True,
+                                   user_defined_symbols=["<image>", "</image>", "<slice>", "</slice>"], minloglevel=2)
+    (tmp_path / "tokenizer_config.json").write_text('{"add_bos_token": true, "add_eos_token": false}')
+    tok = SentencePieceTokenizer.from_pretrained(str(tmp_path))
+    sp = tok.sp_model
+    for attr in ("im_start", "im_end", "unk_token", "slice_start", "slice_end", "add_bos_token", "bos_id", "eos_id", "unk_id",
+                 "im_start_id", "im_end_id", "encode"):
+        assert hasattr(tok, attr), attr
+    assert (tok.unk_id, tok.bos_id, tok.eos_id) == (0, 1, 2) and tok.unk_token == "<unk>"
+    assert tok.im_start_id == sp.piece_to_id("<image>") != 0 and tok.im_end_id == sp.piece_to_id("</image>") != 0
+    # the placeholder of a page: bos, <image>, 64 x unk, </image> — exactly query_num ids between the markers (the reference's
+    # scatter needs that) — then "\n" as its byte piece behind the dummy prefix
+    ph = tok.im_start + tok.unk_token * 64 + tok.im_end
+    ids = tok.encode(ph + "\n")
+    assert ids[0] == tok.bos_id
+    body = ids[1:]
+    i0 = body.index(tok.im_start_id)
+    assert i0 == 0
+    assert body[i0 + 1:i0 + 65] == [0] * 64 and body[i0 + 65] == tok.im_end_id
+    assert sp.piece_to_id("<0x0A>") in body[i0 + 66:]                     # identity normaliser: the newline survives as a byte
+    # text pieces are encoded on their own: the legacy behaviour re-inserts the dummy prefix after a special token
+    text = "revenue table"
+    assert tok.encode(text) == [1] + sp.encode(text)
+    assert tok.encode("<unk>" + text) == [1, 0] + sp.encode(text)
+    assert tok.encode(text + "</s>" + text) == [1] + sp.encode(text) + [2] + sp.encode(text)
+    assert tok.decode(tok.encode(text)[1:]) == text
+    # through the host side of the path: ids / image_bound agree with the marker positions
+    cfg = tiny_config()
+    cfg.vocab_size = tok.vocab_size
+    page = Image.fromarray(synth_pages(1, size=cfg.scale_resolution, seed=0)[0])
+    items = prepare_batch(["a caption about revenue", "Represent this query for retrieving relevant documents: annual report"],
+                          [page, None], tok, cfg, 2048)
+    it = items[0]
+    starts = [i for i, t in enumerate(it.input_ids) if t == tok.im_start_id]
+    ends = [i for i, t in enumerate(it.input_ids) if t == tok.im_end_id]
+    assert len(starts) == len(ends) == len(it.image_bound) == len(it.slices) == 1
+    assert [tuple(b) for b in it.image_bound] == [(s + 1, e) for s, e in zip(starts, ends)]
+    assert all(t == tok.unk_id for t in it.input_ids[starts[0] + 1:ends[0]]) and ends[0] - starts[0] - 1 == cfg.query_num
+    assert items[1].image_bound == [] or len(items[1].image_bound) == 0
+    assert max(items[1].input_ids) < tok.vocab_size and items[1].input_ids[0] == tok.bos_id
+    with pytest.raises(ValueError):                                           # a model without the markers is refused
+        spm.SentencePieceTrainer.train(sentence_iterator=iter(sents), model_prefix=prefix + "_plain", vocab_size=300, model_type="bpe",
+                                       byte_fallback=True, character_coverage=1.0, minloglevel=2)
+        SentencePieceTokenizer(prefix + "_plain.model")
+
+
+def test_prefetched_batches_order_errors_and_worker_modes():
+    """inference._prefetched_batches (the DataLoader's role: inference.py:66-73): same batches in the same order on the
+    calling thread, from a map-style dataset through a thread pool and from a plain iterable through a loader thread; an
+    error in the loader surfaces in the consumer; PIL pages become u8 arrays in the loader when asked."""
+    import threading
+    from PIL import Image
+    from visrag_amd.inference import _prefetched_batches
+
+    class MapDS:
+        def __init__(self): self.threads = set()
+        def __len__(self): return 23
+        def __getitem__(self, i):
+            if i >= 23:
+                raise IndexError(i)
+            self.threads.add(threading.current_thread().name)
+            return {"id": str(i), "text": f"t{i}", "image": Image.new("L", (4, 3), i) if i % 2 else None}
+
+    def gen():
+        for i in range(23):
+            yield {"id": str(i), "text": f"t{i}", "image": None}
+
+    ref = [b["id"] for b in _prefetched_batches(MapDS(), 5, 0)]
+    assert ref == [[str(i) for i in range(lo, min(23, lo + 5))] for lo in range(0, 23, 5)]
+    ds = MapDS()
+    got = list(_prefetched_batches(ds, 5, 3, to_u8=True))
+    assert [b["id"] for b in got] == ref and all(t.startswith("visrag-loader") for t in ds.threads)
+    im = got[0]["image"][1]
+    assert isinstance(im, np.ndarray) and im.shape == (3, 4, 3) and im.dtype == np.uint8 and (im == 1).all() and got[0]["image"][0] is None
+    assert [b["id"] for b in _prefetched_batches(gen(), 5, 2)] == ref
+
+    def bad():
+        yield {"id": "0", "text": "", "image": None}
+        raise RuntimeError("decode failed")
+    with pytest.raises(RuntimeError, match="decode failed"):
+        list(_prefetched_batches(bad(), 1, 1))

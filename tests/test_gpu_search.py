@@ -417,6 +417,20 @@ full = HipIndex(dim, nd, device=rank); full.add(torch.from_numpy(C).cuda())
 fs, fi = full.search(q, k)
 torch.cuda.synchronize()
 assert torch.equal(ids, fi) and torch.equal(sc, fs), rank
+# the same transport behind the kept API: distributed_parallel_retrieve, corpus-sharded == replicated
+import types
+from visrag_amd.retriever import distributed_parallel_retrieve
+from visrag_amd.utils import shard_name, write_shard
+out = os.environ["VR_OUT"]
+write_shard(os.path.join(out, shard_name("corpus", rank)), C[lo:hi], [f"d{i}" for i in range(lo, hi)])
+qper = (nq + world - 1) // world
+write_shard(os.path.join(out, shard_name("query", rank)), Q[rank * qper:(rank + 1) * qper], [f"q{i}" for i in range(rank * qper, min(nq, (rank + 1) * qper))])
+dist.barrier()
+args = types.SimpleNamespace(output_dir=out, process_index=rank, device=f"cuda:{rank}")
+for gt in (False, True):
+    ref = distributed_parallel_retrieve(args, k, global_topk=gt, sharded=False)
+    got = distributed_parallel_retrieve(args, k, global_topk=gt, sharded=True)
+    assert got == ref and list(got) == list(ref), (rank, gt)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -436,7 +450,7 @@ def test_sharded_search_over_rccl(tmp_path):
     procs = []
     for r in range(n):
         env = dict(os.environ, VR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(n),
-                   LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0", VR_OUT=str(tmp_path))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -578,3 +592,65 @@ def test_contiguous_near_duplicate_block_goes_through_the_band_pass(n_dup, nq):
     keys = ix.search_keys(torch.from_numpy(Q).cuda(), k, id_offset=7)
     us, ui = unpack_keys_host(keys.cpu().numpy())
     assert np.array_equal(ui, ids + 7) and np.array_equal(us, sc)
+
+
+RETRIEVE_SHARD_WORKER = r'''
+import os, sys, types
+sys.path.insert(0, os.environ["VR_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from visrag_amd.retriever import distributed_parallel_retrieve
+from visrag_amd.utils import save_as_trec
+rank = int(os.environ["VR_RANK"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["VR_PORT"], rank=rank, world_size=2)
+torch.cuda.set_device(0)
+calls = {"n": 0}
+real_gather = dist.all_gather_into_tensor
+def counting_gather(*a, **k):
+    calls["n"] += 1
+    return real_gather(*a, **k)
+dist.all_gather_into_tensor = counting_gather
+out = os.environ["VR_OUT"]
+args = types.SimpleNamespace(output_dir=out, process_index=rank, device="cuda:0")
+for k in (10, 40):                                        # fused sweep and the deep path
+    for gt in (False, True):
+        ref = distributed_parallel_retrieve(args, k, global_topk=gt, sharded=False)      # every rank: ALL corpus shards (the reference)
+        n0 = calls["n"]
+        got = distributed_parallel_retrieve(args, k, global_topk=gt, sharded=True)       # rank r: only the shards rank r wrote
+        assert calls["n"] == n0 + 1, calls
+        assert got == ref and list(got) == list(ref), (rank, k, gt)
+        save_as_trec(ref, os.path.join(out, f"ref.{rank}.{k}.{gt}.trec")); save_as_trec(got, os.path.join(out, f"got.{rank}.{k}.{gt}.trec"))
+        a = open(os.path.join(out, f"ref.{rank}.{k}.{gt}.trec"), "rb").read(); b = open(os.path.join(out, f"got.{rank}.{k}.{gt}.trec"), "rb").read()
+        assert a == b and len(a) > 0, (rank, k, gt)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_corpus_sharded_retrieve_two_ranks_on_one_gpu(tmp_path):
+    """Row g on the device: two processes (sharing the one GPU, gloo rendezvous), each loading ONLY its own corpus shards
+    into a real HipIndex behind `distributed_parallel_retrieve(sharded=True)` — equal to the replicated form (every rank
+    loads everything: what the reference does) dict for dict and TREC byte for byte; union and global top-k; k = 10 (fused
+    sweep) and 40 (deep path); rank 0 wrote two split files, one of rank 1's rows duplicates one of rank 0's."""
+    import socket, subprocess, sys
+    from visrag_amd.utils import shard_name, write_shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dim, nd, nq = 512, 9000, 70
+    C, Q = _unit(nd, dim, 91), _unit(nq, dim, 92)
+    C[8000] = C[17]
+    docs = [f"doc{i}" for i in range(nd)]
+    out = tmp_path / "emb"; out.mkdir()
+    write_shard(str(out / shard_name("corpus", 0, 0, 3000)), C[:3000], docs[:3000])
+    write_shard(str(out / shard_name("corpus", 0, 3000, 5000)), C[3000:5000], docs[3000:5000])
+    write_shard(str(out / shard_name("corpus", 1)), C[5000:], docs[5000:])
+    write_shard(str(out / shard_name("query", 0)), Q[:40], [f"q{i}" for i in range(40)])
+    write_shard(str(out / shard_name("query", 1)), Q[40:], [f"q{i}" for i in range(40, nq)])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(RETRIEVE_SHARD_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, VR_ROOT=root, VR_PORT=str(port), VR_RANK=str(r), VR_OUT=str(out))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

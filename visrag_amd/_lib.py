@@ -159,4 +159,4 @@ def make_config(cfg, max_images: int, max_patches: int, max_tokens: int, max_seq
         vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
         scale_emb=cfg.scale_emb, residual_scale=cfg.residual_scale, max_images=max_images,
         max_patches=max_patches, max_tokens=max_tokens, max_seqs=max_seqs,
-        text_split_precision=1 if getattr(cfg, "text_split_precision", True) else 0)
+        text_split_precision=int(getattr(cfg, "text_split_precision", True)))

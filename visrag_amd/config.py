@@ -44,7 +44,9 @@ class VisRAGRetConfig:
     slice_mode: bool = True
     # engine option (not a checkpoint field): token-only batches run the decoder at fp32-class precision
     # (hi + lo bf16 operand splits; csrc/hp_text.hip) — what keeps ~20-token queries inside the 1e-3 score bar
-    text_split_precision: bool = True
+    # True / 1: every token-only batch; False / 0: never; N > 1: only batches whose longest sequence has <= N tokens
+    # (e.g. 512, the reference's query length — long text passages then keep the bf16 MFMA attention path)
+    text_split_precision: int = True
     # pooling of DRModel.encode (dense_retrieval_model.py:150-223): wmean | mean | lasttoken | cls | drop_wmean | drop_mean
     pooling: str = "wmean"
 

@@ -859,8 +859,15 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         HIPCHK(hipMemcpyAsync(m->w_ids.p, a_ids, (size_t)T * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(m->w_seq.p, a_seq, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
     }
-    // token-only batches (queries, text passages) take the split-precision decoder pass (hp_text.hip)
-    const bool hp = n_slices == 0 && c.text_split_precision != 0;
+    // token-only batches (queries, text passages) take the split-precision decoder pass (hp_text.hip).
+    // text_split_precision: 0 = never, 1 = every token-only batch, N > 1 = only batches whose longest sequence has at most N
+    // tokens (e.g. 512 = the reference's query length: long text passages then stay on the bf16 MFMA flash-attention path,
+    // whose cost grows with L instead of L^2 waves).  NOTE the batch-composition dependence this implies: the same text item
+    // is embedded at fp32-class precision in a token-only batch and at bf16 precision (inside the 1e-3 tolerance, not the
+    // 1e-6 of the split pass) in a batch that also holds an image.
+    int max_len = 0;
+    for (int i = 0; i < B; ++i) max_len = std::max(max_len, seq_offsets[i + 1] - seq_offsets[i]);
+    const bool hp = n_slices == 0 && c.text_split_precision != 0 && (c.text_split_precision == 1 || max_len <= c.text_split_precision);
     if (hp && m->has_embed_lo)
         HIPCHK(launch_embed_gather_hp(m->w_ids.as<int>(), T, m->embed.p, m->embed_lo.p, E, c.scale_emb, m->w_h.as<float>(), s));
     else
@@ -919,8 +926,6 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
     // ---- decoder (modeling_minicpm.py:939-1004, 1147-1304), packed ragged sequences
     float* h = m->w_h.as<float>();
     const int* seq = m->w_seq.as<int>();
-    int max_len = 0;
-    for (int i = 0; i < B; ++i) max_len = std::max(max_len, seq_offsets[i + 1] - seq_offsets[i]);
     if (max_len > m->rope_len) return fail(VR_ERR_CAPACITY, "sequence of %d tokens exceeds the RoPE table", max_len);
     VRCHK(prof_begin(m, VR_PROF_DECODER, s));
     if (hp) {
@@ -976,6 +981,8 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         return VR_OK;
     };
     auto norm = [&](const float* w) -> int {
+        VRCHK(prof_begin(m, VR_PROF_DEC_NORM, s));
+        struct End { vr_model_s* m; hipStream_t s; ~End() { (void)prof_end(m, VR_PROF_DEC_NORM, 0.0, s); } } end_{m, s};
         if (pend) {
             HIPCHK(launch_rmsnorm_accum(h, T, E, E, part, ks, pstride, E, c.residual_scale, w, c.rms_norm_eps, m->w_dxn.p, E, s));
             pend = false;
@@ -984,26 +991,38 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         }
         return VR_OK;
     };
+    double attn_flops = 0;
+    for (int i = 0; i < B; ++i) { const double Li = seq_offsets[i + 1] - seq_offsets[i]; attn_flops += 4.0 * Li * Li * E; }
     for (int l = 0; l < c.num_layers; ++l) {
         const DecLayer& L = m->layers[l];
         VRCHK(norm(L.ln1.v.as<float>()));
         {
             GemmArgs a = gemm_args(m->w_dxn.p, E, L.qkv, T, m->w_dqkv.p, 3 * E);
             a.rope_pos = m->w_pos.as<int>(); a.rope_table = m->rope.as<float>(); a.rope_cols = 2 * E;
+            VRCHK(prof_begin(m, VR_PROF_DEC_QKV, s));
             HIPCHK(launch_gemm(a, EPI_ROPE, GEMM_VARIANT_AUTO, s));
+            VRCHK(prof_end(m, VR_PROF_DEC_QKV, 6.0 * T * (double)E * E, s));
         }
         {
+            VRCHK(prof_begin(m, VR_PROF_DEC_ATTN, s));
             AttnArgs a{};
             a.q = m->w_dqkv.p; a.ldq = 3 * E; a.k = (const char*)m->w_dqkv.p + (size_t)E * 2; a.ldk = 3 * E;
             a.v = (const char*)m->w_dqkv.p + (size_t)2 * E * 2; a.ldv = 3 * E;
             a.out = m->w_datt.p; a.ldo = E; a.cu_q = seq; a.cu_kv = seq; a.B = B; a.heads = c.num_heads; a.head_dim = 64;
             a.max_q = max_len; a.causal = 1; a.q_shared = 0; a.scale = 1.0f / sqrtf(64.0f);
             HIPCHK(launch_attention(a, s));
+            VRCHK(prof_end(m, VR_PROF_DEC_ATTN, attn_flops, s));
         }
+        VRCHK(prof_begin(m, VR_PROF_DEC_O, s));
         VRCHK(proj(m->w_datt.p, E, L.o, true));
+        VRCHK(prof_end(m, VR_PROF_DEC_O, 2.0 * T * (double)E * E, s));
         VRCHK(norm(L.ln2.v.as<float>()));
+        VRCHK(prof_begin(m, VR_PROF_DEC_GU, s));
         { GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
+        VRCHK(prof_end(m, VR_PROF_DEC_GU, 4.0 * T * (double)E * m->I, s));
+        VRCHK(prof_begin(m, VR_PROF_DEC_DOWN, s));
         VRCHK(proj(m->w_dact.p, m->Ip, L.down));
+        VRCHK(prof_end(m, VR_PROF_DEC_DOWN, 2.0 * T * (double)E * m->I, s));
         if (l == 0) VRCHK(tap_store(m, "dec_layer0", h, T, E, E, false, s));
     }
     if (pend) {                          // last down projection: residual update only

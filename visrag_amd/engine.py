@@ -162,7 +162,8 @@ class HipEncoder:
         return out
 
     # ---- profiling (HIP events around kernel classes, see include/visrag_hip.h) -------------
-    PROF_CLASSES = ("vit_qkv", "vit_attn", "vit_proj", "vit_fc1", "vit_fc2", "resampler", "decoder")
+    PROF_CLASSES = ("vit_qkv", "vit_attn", "vit_proj", "vit_fc1", "vit_fc2", "resampler", "decoder",
+                    "dec_qkv_rope", "dec_attn", "dec_o", "dec_gate_up", "dec_down", "dec_norms")
 
     def set_profile(self, on: bool) -> None:
         _lib.check(self.lib.vr_model_set_profile(self._h, 1 if on else 0))
