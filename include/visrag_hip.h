@@ -159,6 +159,8 @@ int vr_model_set_taps(vr_model_t m, int32_t enable);
 #define VR_PROF_DEC_DOWN 11  /* down projection                                         */
 #define VR_PROF_DEC_NORM 12  /* RMSNorm passes (incl. the split-K accumulate)           */
 #define VR_PROF_CLASSES 13
+/* enable: 0 off, 1 the phase classes 0..6, 2 the decoder's sub-phases 7..12 instead (their events sit between the decoder's
+ * kernels and would lengthen VR_PROF_DECODER if both were taken in one pass) */
 int vr_model_set_profile(vr_model_t m, int32_t enable);
 int vr_model_get_profile(vr_model_t m, int32_t cls, double* total_ms, int64_t* launches,
                          double* total_flops);

@@ -24,11 +24,24 @@ with tempfile.TemporaryDirectory() as td:
     a = types.SimpleNamespace(output_dir=td, per_device_eval_batch_size=B, process_index=0, world_size=1, max_inmem_docs=10_000_000,
                               device="cuda:0")
     distributed_parallel_embedding_inference(corpus[:2 * B], model, a, "corpus", False, extra)
-    for rep in range(2):
+    host = {"t": 0.0, "n": 0}
+    fwd = model.forward
+
+    def timed_forward(*aa, **kk):          # time the calling thread spends inside model(...): host prepare + launches
+        t = time.perf_counter()
+        r = fwd(*aa, **kk)
+        host["t"] += time.perf_counter() - t; host["n"] += 1
+        return r
+    model.forward = timed_forward
+    model.__class__.__call__ = lambda self, *aa, **kk: self.forward(*aa, **kk)
+    for workers in (0, 1, 4, 1):
+        a.dataloader_num_workers = workers
+        host["t"], host["n"] = 0.0, 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
         distributed_parallel_embedding_inference(corpus, model, a, "corpus", False, extra)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"pil_pipeline: {n / dt:.1f} pages/s ({dt / (n / B) * 1e3:.1f} ms per batch of {B})", flush=True)
+        print(f"pil_pipeline workers={workers}: {n / dt:.1f} pages/s ({dt / (n / B) * 1e3:.1f} ms per batch of {B}; "
+              f"{host['t'] / max(host['n'], 1) * 1e3:.1f} ms of it inside model(...) on the calling thread)", flush=True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for lo in range(0, n, B):
     [prepare_item_gpu("", c["image"], tok, cfg, 2048, 0) for c in corpus[lo:lo + B]]

@@ -75,6 +75,7 @@ struct vr_model_s {
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
     // stream, elapsed times summed lazily in vr_model_get_profile
     bool prof_on = false;
+    int prof_level = 0;                       // 1: the seven phase classes; 2: the decoder's sub-phases instead (events between its kernels)
     struct ProfClass { std::vector<hipEvent_t> ev; size_t used = 0; double ms = 0, flops = 0; int64_t launches = 0; };
     ProfClass prof[VR_PROF_CLASSES];
     // pinned host arena for the small per-call arrays (ids, offsets, row maps, image pointers):
@@ -104,7 +105,7 @@ static void* arena_take(vr_model_s* m, size_t bytes) {
 }
 
 static int prof_begin(vr_model_s* m, int cls, hipStream_t s) {
-    if (!m->prof_on) return VR_OK;
+    if (!m->prof_on || (cls >= VR_PROF_DEC_QKV) != (m->prof_level == 2)) return VR_OK;
     auto& p = m->prof[cls];
     if (p.used + 2 > p.ev.size()) {
         for (int i = 0; i < 64; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); p.ev.push_back(e); }
@@ -113,7 +114,7 @@ static int prof_begin(vr_model_s* m, int cls, hipStream_t s) {
     return VR_OK;
 }
 static int prof_end(vr_model_s* m, int cls, double flops, hipStream_t s) {
-    if (!m->prof_on) return VR_OK;
+    if (!m->prof_on || (cls >= VR_PROF_DEC_QKV) != (m->prof_level == 2)) return VR_OK;
     auto& p = m->prof[cls];
     HIPCHK(hipEventRecord(p.ev[p.used + 1], s));
     p.used += 2; p.launches += 1; p.flops += flops;
@@ -1079,6 +1080,7 @@ extern "C" int vr_model_set_profile(vr_model_t m, int32_t enable) {
     VRCHK(set_dev(m->device));
     VRCHK(prof_collect(m));
     m->prof_on = enable != 0;
+    m->prof_level = enable == 2 ? 2 : (enable ? 1 : 0);
     for (auto& p : m->prof) { p.ms = 0; p.flops = 0; p.launches = 0; p.used = 0; }
     return VR_OK;
 }

@@ -165,8 +165,9 @@ class HipEncoder:
     PROF_CLASSES = ("vit_qkv", "vit_attn", "vit_proj", "vit_fc1", "vit_fc2", "resampler", "decoder",
                     "dec_qkv_rope", "dec_attn", "dec_o", "dec_gate_up", "dec_down", "dec_norms")
 
-    def set_profile(self, on: bool) -> None:
-        _lib.check(self.lib.vr_model_set_profile(self._h, 1 if on else 0))
+    def set_profile(self, on) -> None:
+        """False / 0: off; True / 1: the seven phase classes; 2: the decoder's sub-phases (dec_*) instead."""
+        _lib.check(self.lib.vr_model_set_profile(self._h, int(on)))
 
     def get_profile(self) -> Dict[str, Dict[str, float]]:
         out = {}
