@@ -74,6 +74,34 @@ def test_text_queries_split_precision_full_width(wide_model):
     assert _scores_err(got, ref, np.concatenate([U, ref])) < 1e-4
 
 
+def test_single_query_takes_the_weight_streamer_full_width(wide_model):
+    """A batch of at most 32 tokens (one query: the serving case, BASELINE config 5's retrieve step) runs the split-precision
+    decoder pass on the weight-streaming GEMM (gemm_skinny.hip: every projection = ONE pass over its weights per operand
+    half, fp32 split-K planes summed in a fixed order) instead of 128-row tiles: same fp32-class agreement with the
+    oracle, and the embedding of a query alone equals its embedding inside a batch of 16 to fp32 noise."""
+    cfg, W, enc, model = wide_model
+    tok = StandInTokenizer(cfg.vocab_size)
+    texts = ["Represent this query for retrieving relevant documents: " + t for t in synth_queries(16, seed=0)]
+    items = prepare_batch(texts, [None] * 16, tok, cfg, 512)
+    assert all(len(it.input_ids) <= 32 for it in items) and sum(len(it.input_ids) for it in items) > 32
+    batch = model.encode_prepared(items).cpu().numpy()
+    alone = np.concatenate([model.encode_prepared(items[i:i + 1]).cpu().numpy() for i in (0, 5, 15)])
+    ref = _oracle(W, cfg, [items[i] for i in (0, 5, 15)])
+    assert ((alone * ref).sum(1)).min() > 1 - 1e-6, 1 - (alone * ref).sum(1).min()
+    np.testing.assert_allclose(alone, batch[[0, 5, 15]], atol=3e-6, rtol=0)
+    # three short queries in ONE call (22 rows together: still the streamer) == each alone, and a 31-token one
+    short = prepare_batch(synth_queries(3, seed=7, min_words=4, max_words=8), [None] * 3, tok, cfg, 512)
+    assert sum(len(it.input_ids) for it in short) <= 32
+    together = model.encode_prepared(short).cpu().numpy()
+    each = np.concatenate([model.encode_prepared(short[i:i + 1]).cpu().numpy() for i in range(3)])
+    np.testing.assert_allclose(together, each, atol=3e-6, rtol=0)
+    assert ((together * _oracle(W, cfg, short)).sum(1)).min() > 1 - 1e-6
+    long_q = prepare_batch([_words(30, 11)], [None], tok, cfg, 512)
+    assert len(long_q[0].input_ids) == 31
+    got = model.encode_prepared(long_q).cpu().numpy()
+    assert ((got * _oracle(W, cfg, long_q)).sum(1)).min() > 1 - 1e-6
+
+
 def test_long_passage_and_long_query_full_width(wide_model):
     """The reference's maximum lengths: one 2048-token text passage and one 512-token query (both LONGER texts,
     truncated at max_inp_length like modeling_minicpmv.py:179-180), next to a short one in the same batch."""

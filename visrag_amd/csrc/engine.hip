@@ -71,6 +71,7 @@ struct vr_model_s {
     DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact, w_part;   // w_part: split-K partial products [3][T][E] f32
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
     DevBuf w_hp_hi, w_hp_lo, w_hp_qkv, w_hp_att, w_hp_gu, w_seqof;   // split-precision text path (hp_text.hip)
+    DevBuf w_hp_part;                                                 // its split-K planes for short batches (grown on demand)
     std::map<std::string, Tap> taps;
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
     // stream, elapsed times summed lazily in vr_model_get_profile
@@ -181,7 +182,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
                       &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
-                      &m->w_pix, &m->w_out, &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof})
+                      &m->w_pix, &m->w_out, &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part})
         b->free();
     delete m;
     return VR_OK;
@@ -464,6 +465,8 @@ static int alloc_workspace(vr_model_s* m) {
         VRCHK(m->w_hp_att.alloc((size_t)T * E * 4));
         VRCHK(m->w_hp_gu.alloc((size_t)T * pad128(2 * m->I) * 4));
         VRCHK(m->w_seqof.alloc((size_t)T * 4));
+        // split-K planes of the weight-streaming path of short batches: 3 passes x 32 rows x (ksplit * n_pad <= 256 tiles of 256)
+        VRCHK(m->w_hp_part.alloc((size_t)3 * 32 * 65536 * 4));
     }
     return VR_OK;
 }
@@ -760,8 +763,8 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
 // ---- the decoder pass of a token-only batch at fp32-class precision (hp_text.hip) -----------------------------
 // out (+)= alpha * A W^T with A = hi + lo (bf16 halves in w_hp_hi / w_hp_lo, row pitch lda) and W = L (+ Llo):
 // A_hi W_hi, then A_lo W_hi and A_hi W_lo added in place by the residual epilogue of the same MFMA kernels.
-static int hp_gemm(vr_model_s* m, const Linear& L, const Linear& Llo, int lda, int T, float* out, int ldo, bool into_resid,
-                   float alpha, hipStream_t s) {
+static int hp_gemm_tiles(vr_model_s* m, const Linear& L, const Linear& Llo, int lda, int T, float* out, int ldo, bool into_resid,
+                         float alpha, hipStream_t s) {
     {
         GemmArgs a = gemm_args(m->w_hp_hi.p, lda, L, T, out, ldo);
         if (into_resid) { a.resid = out; a.alpha = alpha; }
@@ -780,6 +783,43 @@ static int hp_gemm(vr_model_s* m, const Linear& L, const Linear& Llo, int lda, i
     return VR_OK;
 }
 
+// The same product for a SHORT batch (T <= 32 rows: one query, a few queries): the tile GEMMs above run a 128-row tile with
+// a row in five real and stream a projection's weights through ~50 workgroups (0.55 TB/s: 20 ms for one query, 11 GB of
+// weights).  Here every pass is ONE launch of the weight streamer (gemm_skinny.hip, 4-6 TB/s) writing fp32 split-K planes —
+// A_hi W_hi | A_lo W_hi | A_hi W_lo into consecutive plane groups — and one launch sums them (fixed order) into `out`.
+static int choose_stream_ksplit(int n_pad, int k_pad) {
+    const int tiles = (n_pad + 255) / 256, nk = k_pad / 64;
+    int best = 1;
+    for (int d = 2; d <= 32 && tiles * d <= 256; ++d) {
+        const int per = (nk + d - 1) / d;
+        if (per >= 4 && (d - 1) * per < nk) best = d;
+    }
+    return best;
+}
+static int hp_gemm_stream(vr_model_s* m, const Linear& L, const Linear& Llo, int lda, int T, float* out, int ldo, bool into_resid,
+                          float alpha, hipStream_t s) {
+    const int ks = choose_stream_ksplit(L.n_pad, L.k_pad);
+    const size_t plane = (size_t)T * L.n_pad;
+    const int n_pass = Llo.has_w ? 3 : 2;
+    if ((size_t)n_pass * ks * plane * 4 > m->w_hp_part.bytes) return fail(VR_ERR_CAPACITY, "split-K planes exceed the workspace");
+    float* part = m->w_hp_part.as<float>();
+    for (int pass = 0; pass < n_pass; ++pass) {
+        GemmArgs a = gemm_args(pass == 1 ? m->w_hp_lo.p : m->w_hp_hi.p, lda, pass == 2 ? Llo : L, T, part + (size_t)pass * ks * plane, L.n_pad);
+        a.bias = nullptr;
+        a.ksplit = ks; a.split_stride = plane;
+        HIPCHK(launch_gemm_skinny(a, s));
+    }
+    HIPCHK(launch_planes_sum(part, n_pass * ks, plane, L.n_pad, T, std::min(L.n_pad, ldo), out, ldo, into_resid ? alpha : 1.0f, into_resid, s));
+    return VR_OK;
+}
+static bool hp_stream_ok(const vr_model_s* m, int T) {
+    if (T > 32) return false;
+    for (const DecLayer& L : m->layers)
+        for (const Linear* l : {&L.qkv, &L.o, &L.gu, &L.down})
+            if (l->n_pad % 256 || l->k_pad % 64 || l->has_b) return false;     // 256-column tiles of the streamer; no bias in this decoder
+    return true;
+}
+
 static int run_decoder_hp(vr_model_s* m, int T, int B, int max_len, hipStream_t s) {
     (void)max_len;
     const vr_config_t& c = m->c;
@@ -790,6 +830,12 @@ static int run_decoder_hp(vr_model_s* m, int T, int B, int max_len, hipStream_t 
     float* gu = m->w_hp_gu.as<float>();
     const int ld_gu = pad128(2 * I);
     HIPCHK(launch_seq_of(m->w_seq.as<int>(), B, m->w_seqof.as<int>(), s));
+    const bool stream = hp_stream_ok(m, T);
+    auto hp_gemm = [&](vr_model_s* mm, const Linear& L, const Linear& Llo, int lda, int TT, float* out, int ldo, bool into_resid,
+                       float alpha, hipStream_t ss) -> int {
+        return stream ? hp_gemm_stream(mm, L, Llo, lda, TT, out, ldo, into_resid, alpha, ss)
+                      : hp_gemm_tiles(mm, L, Llo, lda, TT, out, ldo, into_resid, alpha, ss);
+    };
     for (int l = 0; l < c.num_layers; ++l) {
         const DecLayer& L = m->layers[l];
         HIPCHK(launch_rmsnorm_split(h, T, E, L.ln1.v.as<float>(), c.rms_norm_eps, m->w_hp_hi.p, m->w_hp_lo.p, s));
@@ -1061,7 +1107,7 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
                       &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out,
-                      &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof}) {
+                      &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part}) {
         b->free();                                 // (a non-owning alias after the copy: just forget it)
     }
     m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)

@@ -247,14 +247,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         bool plain_resid = false;
         if constexpr (EPI == EPI_RESID) plain_resid = !p.rowmap;
         if constexpr (EPI == EPI_RESID) {
-            // out = resid + alpha * (acc + bias), fp32, in place: the residual of piece q + 1 is requested before
-            // piece q is combined and stored, so (one wave per SIMD, nothing else to hide it) only the first piece's
-            // load latency is exposed.  Addresses are clamped for rows >= M / columns >= N, the stores predicated.
+            // out = resid + alpha * (acc + bias), fp32, in place, piece by piece (below).  Addresses are clamped for
+            // rows >= M / columns >= N, the stores predicated.
             if (plain_resid) {
                 constexpr int MI = 2;           // pieces of 32 rows x 16 NF columns: 8 per wave
                 const float* __restrict__ resid = p.resid;
                 float* __restrict__ out = (float*)p.out;
-                f32x4 rs[2][MI][NF];
+                // The residual of piece q + RD is requested before piece q is combined and stored (one wave per SIMD, nothing else
+                // hides the latency).  RD = 1 is enough: round 4 measured RD = 1 .. 6 in-model on one box (the ring lives in the
+                // K-loop's dead fragment registers) — proj 3.31-3.36 ms, fc2 7.89-8.00 ms per step for every depth — while the
+                // same epilogue WITHOUT its reads runs proj at 2.35 / fc2 at 7.02 and WITHOUT its stores at 2.50 / 6.94, and an
+                // early touch of the residual lines into the L2 is slower (3.53 / 8.42).  So the read-modify-write is paced by
+                // the HBM moving 302 MB per launch in the epilogue phases of the rounds (all CUs leave their K-loops together:
+                // ~3.8 TB/s of mixed reads and writes there, nothing during the K-loops), not by the depth of this wave's
+                // prefetch; overlapping it needs the NEXT tile's K-loop on the same CU, i.e. a second accumulator set.
+#ifndef VR_W_RESID_DEPTH
+#define VR_W_RESID_DEPTH 1
+#endif
+                // (the 256-column tile keeps 256 accumulators: a ring deeper than 3 of its 32-register pieces does not fit beside them)
+                constexpr int RD = NJ == 6 ? VR_W_RESID_DEPTH : (VR_W_RESID_DEPTH < 3 ? VR_W_RESID_DEPTH : 3);
+                f32x4 rs[RD + 1][MI][NF];
                 auto load_piece = [&](int q, f32x4 (&dst)[MI][NF]) {
                     const int h = q & 1, sg = q >> 1;
 #pragma unroll
@@ -270,7 +282,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         }
                     }
                 };
-                load_piece(0, rs[0]);
+#pragma unroll
+                for (int q = 0; q < RD; ++q) load_piece(q, rs[q]);
                 f32x4 bias[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int h = q & 1, sg = q >> 1;
-                    if (q < 7) load_piece(q + 1, rs[(q + 1) & 1]);
+                    if (q + RD < 8) load_piece(q + RD, rs[(q + RD) % (RD + 1)]);
                     f32x4 acc[MI][NF];
 #define W_RD(n, R, C0, C1, C2, C3) \
                     if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
@@ -291,12 +304,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         for (int j = 0; j < NF; ++j) {
                             const int n = nb0 + (h * NF + j) * 16 + fq * 4;
 #if defined(VR_W_RESID_DIAG) && VR_W_RESID_DIAG == 2      // diagnostic build: no stores (WRONG results)
-                            const f32x4 vv = rs[q & 1][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
+                            const f32x4 vv = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
                             if (m < p.M && n < p.N && vv[0] == 123456.78f)
                                 *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = vv;
 #else
                             if (m < p.M && n < p.N)
-                                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q & 1][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
+                                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
 #endif
                         }
                     }

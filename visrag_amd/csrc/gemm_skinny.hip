@@ -1,4 +1,5 @@
-// bf16 GEMM for M <= 16 rows: the generator's decode step, where a GEMM is a pass over the weights.
+// bf16 GEMM for M <= 16 rows (MB = 2: M <= 32): the generator's decode step and the retriever's single-query path,
+// where a GEMM is a pass over the weights.
 //
 //   out[split][m][n] = A[m, Ks] * W[n, Ks]^T      (fp32 partial planes, summed by their consumer)
 //
@@ -21,9 +22,9 @@ namespace vr {
 namespace {
 
 constexpr int SK_STAGES = 4;
-constexpr int SK_W_BYTES = 256 * 128, SK_A_BYTES = 16 * 128;
-constexpr int SK_STAGE = SK_W_BYTES + SK_A_BYTES;
-constexpr int SK_SMEM = SK_STAGES * SK_STAGE;
+constexpr int SK_W_BYTES = 256 * 128;
+constexpr int sk_stage(int mb) { return SK_W_BYTES + mb * 16 * 128; }      // 32 KiB of W + 2 KiB of A per 16 rows
+constexpr int sk_smem(int mb) { return SK_STAGES * sk_stage(mb); }
 constexpr unsigned SK_OOB = 0x80000000u;
 // cache policy of the weight loads: nt (aux bit 1) — every byte of W is read once, by one CU
 #ifndef VR_SKINNY_W_AUX
@@ -39,8 +40,12 @@ constexpr int SK_W_AUX = VR_SKINNY_W_AUX;
 // row 0 of every K-step's A stage is built in the prologue from the partial attention rows of the step's KV ranges,
 //     A[col] = sum_s 2^(lse_s - max) part_s[col] / sum_s 2^(lse_s - max)   per query head (attn_combine_kernel's sum; layout: kernels.h)
 // one lane per column, one wave per K-step: the launch that used to merge the ranges is gone.
-template <bool SWIGLU, bool COMBINE>
+// MB = 2 (plain planes only): 32 rows per pass — two 16-row MFMA row blocks share every W fragment; the A stage has four
+// 8-row groups, one per wave (same nine loads per wave and K-step).
+template <bool SWIGLU, bool COMBINE, int MB = 1>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyCombine cb) {
+    static_assert(MB == 1 || (MB == 2 && !SWIGLU && !COMBINE), "32-row passes write plain fp32 planes");
+    constexpr int SK_STAGE = sk_stage(MB);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = (p.N + 255) / 256;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
@@ -60,7 +65,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyComb
     const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
     const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
     const unsigned rgW = (unsigned)p.ldw * 16u;
-    const unsigned sW0 = (unsigned)wave * 8u * rgW, sA0 = (unsigned)(wave & 1) * (unsigned)p.lda * 16u;
+    const int agrp = MB == 2 ? wave : (wave & 1);                     // this wave's 8-row group of the A stage
+    const unsigned sW0 = (unsigned)wave * 8u * rgW, sA0 = (unsigned)agrp * (unsigned)p.lda * 16u;
     auto issue = [&](int kt) {                      // the 9 loads of K-step kt into stage kt % 4
         char* st = smem + (kt & (SK_STAGES - 1)) * SK_STAGE;
         const unsigned kb = kt < nk ? (unsigned)kt * (GEMM_BK * 2) : SK_OOB;
@@ -68,11 +74,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyComb
         for (int d = 0; d < 8; ++d)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(st + wave * 8192 + d * 1024), 16, lofW + kb, sW0 + d * rgW, 0, SK_W_AUX);
         if constexpr (!COMBINE)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(st + SK_W_BYTES + (wave & 1) * 1024), 16, lofA + kb, sA0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(st + SK_W_BYTES + agrp * 1024), 16, lofA + kb, sA0, 0, 0);
     };
-    f32x4 acc[4];
+    f32x4 acc[MB][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // COMBINE: the partial rows and their log-sum-exps are requested BEFORE the weight stream (loads return in order: asked
     // for after it, they would wait behind three K-steps of weights), merged while the weights are in flight
     float cl[GEN_ATT_SPLITS], cpv[GEN_ATT_SPLITS];
@@ -119,16 +127,24 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyComb
         const char* st = smem + (kt & (SK_STAGES - 1)) * SK_STAGE;
         const char* wr = st + (wave * 64 + fr) * 128;
         const char* ar = st + SK_W_BYTES + fr * 128;
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ar + ch0), a1 = *reinterpret_cast<const bf16x8*>(ar + ch1);
+        bf16x8 a0[MB], a1[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            a0[b] = *reinterpret_cast<const bf16x8*>(ar + b * 2048 + ch0);
+            a1[b] = *reinterpret_cast<const bf16x8*>(ar + b * 2048 + ch1);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wr + j * 2048 + ch0);
             const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wr + j * 2048 + ch1);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a0, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a1, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+                acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a0[b], acc[b][j], 0, 0, 0);
+                acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a1[b], acc[b][j], 0, 0, 0);
+            }
         }
     }
-    // acc[j][r] = out[m = fr][n = n0 + wave*64 + j*16 + fq*4 + r]; bias rides with split 0
+    // acc[b][j][r] = out[m = b*16 + fr][n = n0 + wave*64 + j*16 + fq*4 + r]; bias rides with split 0
     if constexpr (SWIGLU) {
         if (fr < p.M) {
             bf16_t* act = (bf16_t*)p.out + (size_t)fr * p.ldo;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyComb
             for (int jj = 0; jj < 2; ++jj) {
                 const int n = n0 + wave * 64 + jj * 32;          // a [16 gate | 16 up] block pair = 16 columns of act
                 if (n < p.N) {
-                    f32x4 g = acc[2 * jj], u = acc[2 * jj + 1];
+                    f32x4 g = acc[0][2 * jj], u = acc[0][2 * jj + 1];
                     if (p.bias) {
                         g += *reinterpret_cast<const f32x4*>(p.bias + n + fq * 4);
                         u += *reinterpret_cast<const f32x4*>(p.bias + n + 16 + fq * 4);
@@ -150,21 +166,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, SkinnyComb
         }
         return;
     }
-    if (fr < p.M) {
-        float* out = (float*)p.out + (size_t)split * p.split_stride + (size_t)fr * p.ldo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wave * 64 + j * 16 + fq * 4;
-            if (n < p.N) {
-                f32x4 v = acc[j];
-                if (p.bias && split == 0) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                *reinterpret_cast<f32x4*>(out + n) = v;
+    for (int b = 0; b < MB; ++b) {
+        const int m = b * 16 + fr;
+        if (m < p.M) {
+            float* out = (float*)p.out + (size_t)split * p.split_stride + (size_t)m * p.ldo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wave * 64 + j * 16 + fq * 4;
+                if (n < p.N) {
+                    f32x4 v = acc[b][j];
+                    if (p.bias && split == 0) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    *reinterpret_cast<f32x4*>(out + n) = v;
+                }
             }
         }
     }
 }
 
-// fp32 planes out[split][M][ldo]; M <= 16 (A and W rows readable up to 16 / the next multiple of 256), K % 64 == 0; split s
+// fp32 planes out[split][M][ldo]; M <= 16, or <= 32 for plain planes (A and W rows readable up to 16 resp. 32 / the next
+// multiple of 256), K % 64 == 0; split s
 // covers K-steps [s * ceil(steps / ksplit), ...) — a split past the end writes a plane of zeros (+ bias for split 0)
 hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu, const SkinnyCombine* combine) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1;
@@ -176,17 +197,22 @@ hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t s, bool swiglu, con
             combine->heads % combine->group) return hipErrorInvalidValue;
     }
     if (swiglu && (ks != 1 || a.N % 32)) return hipErrorInvalidValue;
-    if (a.M > 16 || a.N % 4 || a.K % GEMM_BK || a.rowmap || a.rowbias) return hipErrorInvalidValue;
+    const bool wide = a.M > 16;
+    if (a.M > 32 || (wide && (swiglu || combine)) || a.N % 4 || a.K % GEMM_BK || a.rowmap || a.rowbias) return hipErrorInvalidValue;
     const size_t tn = (a.N + 255) / 256;
-    if (tn * 256 * (size_t)a.ldw * 2 >= (1ull << 31) || 16 * (size_t)a.lda * 2 >= (1ull << 31)) return hipErrorInvalidValue;
+    if (tn * 256 * (size_t)a.ldw * 2 >= (1ull << 31) || 32 * (size_t)a.lda * 2 >= (1ull << 31)) return hipErrorInvalidValue;
     static unsigned long long attr = 0, attr_sw = 0;     // bit d: set on device d
-    static unsigned long long attr_cb = 0;
+    static unsigned long long attr_cb = 0, attr_w = 0;
+    constexpr int SK_SMEM = sk_smem(1);
     if (combine) {
         set_max_dynamic_lds((const void*)gemm_skinny_kernel<false, true>, SK_SMEM, attr_cb);
         hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a, *combine);
     } else if (swiglu) {
         set_max_dynamic_lds((const void*)gemm_skinny_kernel<true, false>, SK_SMEM, attr_sw);
         hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), dim3((unsigned)tn), dim3(256), SK_SMEM, s, a, SkinnyCombine{});
+    } else if (wide) {
+        set_max_dynamic_lds((const void*)gemm_skinny_kernel<false, false, 2>, sk_smem(2), attr_w);
+        hipLaunchKernelGGL((gemm_skinny_kernel<false, false, 2>), dim3((unsigned)(tn * ks)), dim3(256), sk_smem(2), s, a, SkinnyCombine{});
     } else {
         set_max_dynamic_lds((const void*)gemm_skinny_kernel<false, false>, SK_SMEM, attr);
         hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), dim3((unsigned)(tn * ks)), dim3(256), SK_SMEM, s, a, SkinnyCombine{});

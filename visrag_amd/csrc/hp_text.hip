@@ -207,4 +207,30 @@ hipError_t launch_seq_of(const int* seq_offsets, int B, int* seq_of, hipStream_t
     return hipGetLastError();
 }
 
+// out[t][n] = (accumulate ? out[t][n] : 0) + alpha * sum_p parts[p][t][n]: closes the fp32 partial planes of the weight-streaming
+// GEMMs (gemm_skinny.hip) of a short token-only batch — the K splits of the A_hi W_hi, A_lo W_hi (and A_hi W_lo) passes — in
+// a fixed order
+__global__ __launch_bounds__(256) void planes_sum_kernel(const float* __restrict__ parts, int n_parts, size_t stride, int ldp, int N,
+                                                         float* __restrict__ out, int ldo, float alpha, int accumulate) {
+    const int t = blockIdx.y;
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const float* p0 = parts + (size_t)t * ldp + n;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p0);
+    for (int p = 1; p < n_parts; ++p) a += *reinterpret_cast<const f32x4*>(p0 + (size_t)p * stride);
+    float* o = out + (size_t)t * ldo + n;
+    f32x4 r = a * alpha;
+    if (accumulate) r += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = r;
+}
+
+hipError_t launch_planes_sum(const float* parts, int n_parts, size_t stride, int ldp, int T, int N, float* out, int ldo, float alpha,
+                             bool accumulate, hipStream_t s) {
+    if (T <= 0 || n_parts <= 0) return hipSuccess;
+    if (N % 4 || ldp % 4 || ldo % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(planes_sum_kernel, dim3((N / 4 + 255) / 256, T), dim3(256), 0, s, parts, n_parts, stride, ldp, N, out, ldo, alpha,
+                       accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
 }  // namespace vr

@@ -196,6 +196,9 @@ hipError_t launch_swiglu_split(const float* gu, int T, int ld_gu, int I, int ld_
 hipError_t launch_embed_gather_hp(const int* ids, int T, const void* table_hi, const void* table_lo, int dim, float scale,
                                   float* out, hipStream_t s);
 hipError_t launch_seq_of(const int* seq_offsets, int B, int* seq_of, hipStream_t s);
+// out = (accumulate ? out : 0) + alpha * sum of n_parts fp32 planes [T][ldp] (columns < N), fixed order
+hipError_t launch_planes_sum(const float* parts, int n_parts, size_t stride, int ldp, int T, int N, float* out, int ldo, float alpha,
+                             bool accumulate, hipStream_t s);
 
 // ---- synthetic page images (synth.hip; bench / test support): pages first .. first + n - 1 of visrag_amd/synth.py's corpus
 hipError_t launch_synth_pages(uint8_t* out, int n, int size, long long seed, long long first, hipStream_t s);
