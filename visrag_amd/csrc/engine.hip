@@ -1327,13 +1327,16 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
             const int64_t nbp = pad256l(nb);
             const bool prof = ix->prof_on && !bigk;
             if (prof) HIPCHK(hipEventRecord(ix->prof_ev[0], s));
-            // rows >= nb: zeros; also clears the flag counter
-            HIPCHK(launch_f32_to_bf16_pad(q32 + (size_t)q0 * dim, ix->qbf.p, (size_t)nb * dim, (size_t)nbp * dim, s,
-                                          ix->cert.as<int>() + CERT_FLAG));       // (clears both flag counters)
+            // rows >= nb: zeros; also clears the flag counters.  A handful of queries (streaming kernel): converted inside it.
+            const bool conv_in_kernel = !bigk && search_uses_stream(nb, dim);
+            if (!conv_in_kernel)
+                HIPCHK(launch_f32_to_bf16_pad(q32 + (size_t)q0 * dim, ix->qbf.p, (size_t)nb * dim, (size_t)nbp * dim, s,
+                                              ix->cert.as<int>() + CERT_FLAG));   // (clears both flag counters)
             if (prof) HIPCHK(hipEventRecord(ix->prof_ev[1], s));
             SearchArgs a{};
             a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
             a.q_bf16 = ix->qbf.p; a.q_f32 = q32 + (size_t)q0 * dim; a.nq = nb; a.k = k;
+            a.convert_q = conv_in_kernel ? 1 : 0;
             a.eps_data = ix->eps_rel == -2.f ? 1 : 0;
             a.eps_rel = a.eps_data ? 0.f : ix->eps_rel;
             a.acc_rel = search_acc_rel(dim);

@@ -220,6 +220,8 @@ struct SearchArgs {
     int64_t n_docs;
     int dim;
     const void* q_bf16;              // [nq_pad][dim] bf16
+    int convert_q;                   // streaming kernel only: q_bf16 has NOT been filled — every workgroup converts the queries
+                                     // from q_f32 itself, workgroup 0 writes q_bf16 rows [0, nq) and clears the two flag counters
     const float* q_f32;              // [nq][dim]
     int nq, k;
     float* cand_scores; int* cand_ids; int n_chunks;   // workspace [nq_pad][n_chunks][KP]

@@ -192,10 +192,13 @@ __global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict
 // What the lists do NOT hold: a full list (KP entries) may have dropped rows below its last entry —
 // dropB is the largest such last entry; a shorter list holds every row of its chunk that passed the
 // sweep's starting threshold.
-template <int KP>
-__global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
+// NT threads: 1024 for the streaming kernel's handful of queries — the chip is empty next to these <= 16 workgroups, and
+// the fp32 re-scoring of a query's 16..40 candidate rows (9 KB each, a memory round trip per row and wave) is the longest
+// chain of the whole search: sixteen waves take it in one or two rounds instead of four to ten.
+template <int KP, int NT>
+__global__ __launch_bounds__(NT) void search_merge_wg_kernel(SearchArgs p) {
     constexpr int GD = KP + MERGE_GD_EXTRA < 64 ? KP + MERGE_GD_EXTRA : 64;
-    __shared__ uint64_t lm[256];
+    __shared__ uint64_t lm[NT];
     __shared__ uint64_t surv[MERGE_CAP], exact_w[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];
     __shared__ uint64_t thr_s;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
     uint64_t m = KEY_NONE;
     unsigned drop = 0u;                                  // orderable score of the best LAST entry of a full list
     if (tid == 0) drop_s = 0u;
-    for (int c = tid; c < p.n_chunks; c += 256) {
+    for (int c = tid; c < p.n_chunks; c += NT) {
         const int id = ci[c * KP];
         const float sc = cs[c * KP];
         const uint64_t key = id >= 0 ? make_key(sc, (uint32_t)id) : KEY_NONE;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
     if (wave == 0) {
         uint64_t v = lm[lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
+        for (int w = 1; w < NT / 64; ++w) { const uint64_t o = lm[lane + 64 * w]; v = o > v ? o : v; }
         const uint64_t t = shfl_u64(wave_sort_desc(v), GD - 1);
         if (lane == 0) thr_s = t;
     }
@@ -235,13 +238,13 @@ __global__ __launch_bounds__(256) void search_merge_wg_kernel(SearchArgs p) {
     auto gather = [&](uint64_t thr) -> int {
         if (tid == 0) n_s = 0;
         __syncthreads();
-        for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+        for (int e0 = tid; e0 < total; e0 += NT * 8) {
             int id8[8];
             float sc8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = min(e0 + 256 * u, total - 1);
-                id8[u] = (e0 + 256 * u < total) ? ci[e] : -1;
+                const int e = min(e0 + NT * u, total - 1);
+                id8[u] = (e0 + NT * u < total) ? ci[e] : -1;
                 sc8[u] = cs[e];
             }
 #pragma unroll
@@ -355,7 +358,8 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (a.prof_ev && (e = hipEventRecord(a.prof_ev[3], s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(search_merge_wg_kernel<KP>, dim3(a.nq), dim3(256), 0, s, am);
+    if (search_uses_stream(a.nq, a.dim)) hipLaunchKernelGGL((search_merge_wg_kernel<KP, 1024>), dim3(a.nq), dim3(1024), 0, s, am);
+    else hipLaunchKernelGGL((search_merge_wg_kernel<KP, 256>), dim3(a.nq), dim3(256), 0, s, am);
     return hipGetLastError();
 }
 

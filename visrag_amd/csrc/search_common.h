@@ -129,7 +129,8 @@ __device__ __forceinline__ void emit_slot(const SearchArgs& p, int q, int slot, 
 // that turned out to lie above tau), leaves the best 64 of the n sorted in cand; used when the lists themselves
 // are complete down to tau (dropB < tau), so that only a query with more than 64 rows inside the error band —
 // or incomplete lists — pays for the exact pass.
-// Called by all 256 threads of the query's workgroup; cand / coverB / dropB must be visible (barrier).
+// Called by all threads of the query's workgroup (4 waves, or 16 for the handful-of-queries merge: the fp32 re-scoring of the
+// candidates is spread over its waves); cand / coverB / dropB must be visible (barrier).
 // surv / exact_w: LDS[MERGE_CAP] — what regather() gathered (unsorted) and scratch for its exact keys: when more than 64
 // rows lie inside the error band (a cluster of near-duplicate pages) but no more than MERGE_CAP, ALL of them are re-scored
 // here and the top k taken from that — the exact pass over the whole index is for what exceeds even this.
@@ -196,7 +197,7 @@ template <int KP, typename Regather>
 __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
                                              float coverB, float dropB, float* sh_tau, int* sh_x, Regather regather,
                                              const uint64_t* surv, uint64_t* exact_w) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int nv = p.dim >> 2;
     const float* qrow = p.q_f32 + (size_t)q * p.dim;
     f32x4 qv[MERGE_MAXV];
@@ -211,7 +212,7 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
     auto below = [](float bound, float tau) { return bound == -INFINITY || bound < tau; };
     if (tid < 64) exact_s[tid] = KEY_NONE;
     __syncthreads();
-    for (int c = wave; c < KP; c += 4) rescore(c);
+    for (int c = wave; c < KP; c += nw) rescore(c);
     __syncthreads();
     const bool certify = p.eps_data || p.eps_rel >= 0.f;
     if (wave == 0) {
@@ -232,7 +233,7 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
         const int n = regather(tau);
         if (n > 64 && n <= MERGE_CAP && key_score(cand[63]) >= tau) {
             // the band holds more than the 64 sorted candidates, but all n of its rows sit in surv: re-score every one
-            for (int c = wave; c < n; c += 4) {
+            for (int c = wave; c < n; c += nw) {
                 const uint64_t key = surv[c];
                 const uint32_t id = ~(uint32_t)key;
                 const float a = wave_sum(dot_lane(qv, p.index_f32 + (size_t)id * p.dim, nv, lane));
@@ -259,7 +260,7 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
     }
     __syncthreads();
     const int x = *sh_x;
-    for (int c = KP + wave; c < KP + x; c += 4) rescore(c);
+    for (int c = KP + wave; c < KP + x; c += nw) rescore(c);
     __syncthreads();
     if (wave == 0) {
         const uint64_t ex = wave_sort_desc(exact_s[lane]);

@@ -48,8 +48,35 @@ __global__ __launch_bounds__(512) void search_stream_kernel(SearchArgs p, int ro
     for (int c = tid; c < 2 * nps * 64; c += 512) {
         const int step = c >> 6, l = c & 63;
         const int t = step >> 1, h = step & 1, qf = l & 15, qq = l >> 4;
-        const bf16_t* src = (const bf16_t*)p.q_bf16 + (size_t)qf * dim + t * 64 + qq * 16 + h * 8;
-        *reinterpret_cast<u32x4*>(qs + (size_t)c * 16) = *reinterpret_cast<const u32x4*>(src);
+        const size_t o = (size_t)qf * dim + t * 64 + qq * 16 + h * 8;
+        if (p.convert_q) {           // straight from the caller's fp32 rows (the same rounding as launch_f32_to_bf16): no convert launch
+            bf16x8 v;
+            if (qf < p.nq) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.q_f32 + o), b = *reinterpret_cast<const f32x4*>(p.q_f32 + o + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = f2bf(a[r]); v[4 + r] = f2bf(b[r]); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = f2bf(0.f);
+            }
+            *reinterpret_cast<bf16x8*>(qs + (size_t)c * 16) = v;
+        } else {
+            *reinterpret_cast<u32x4*>(qs + (size_t)c * 16) = *reinterpret_cast<const u32x4*>((const bf16_t*)p.q_bf16 + o);
+        }
+    }
+    if (p.convert_q && blockIdx.x == 0) {       // what the convert launch left behind for the merge / band pass
+        bf16_t* qb = (bf16_t*)const_cast<void*>(p.q_bf16);
+        for (int i = tid; i < p.nq * dim / 8; i += 512) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)i * 8), b = *reinterpret_cast<const f32x4*>(p.q_f32 + (size_t)i * 8 + 4);
+            bf16x8 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = f2bf(a[r]); v[4 + r] = f2bf(b[r]); }
+            *reinterpret_cast<bf16x8*>(qb + (size_t)i * 8) = v;
+        }
+        if (tid == 0) {
+            if (p.flag_count) p.flag_count[0] = 0;
+            if (p.flag2_count) p.flag2_count[0] = 0;
+        }
     }
     if (tid < 16) { L.thr[tid] = tid < p.nq ? -INFINITY : INFINITY; L.cnt[tid] = 0; }
     __syncthreads();
