@@ -516,7 +516,7 @@ def main():
                                 "-> 5 pages (448 x 448 u8, host store) -> GPU resize/normalise/patchify -> tower -> prefill (1405 "
                                 "tokens) -> 64 answer tokens; one query at a time, wall clock"}
 
-            result["evisrag_generate"] = bench_generate(5, 64, 2, local_rank, chain=chain)
+            result["evisrag_generate"] = bench_generate(5, 64, 2, local_rank, chain=chain, a4_pages=True)
         except Exception as e:   # informational
             result["evisrag_error"] = repr(e)
 

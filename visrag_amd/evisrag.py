@@ -236,7 +236,7 @@ def iter_synth_gen_weights(cfg: "GenConfig", seed: int = 0, device="cpu", bf16: 
 
 
 def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2, device: int = 0, vision: bool = True,
-                   chain=None) -> dict:
+                   chain=None, a4_pages: bool = False, a4_tokens: int = 2048) -> dict:
     """EVisRAG-7B-shaped generation (BASELINE config 5: the top retrieved pages go to the generator, one query at a
     time like src/evisrag/predict.py:128-149): random weights of Qwen2.5-VL-7B (vision tower + language model), pages
     as the image processor's pixel rows (448 x 448: 32 x 32 patches -> 16 x 16 image tokens).  Returns vision / prefill
@@ -248,8 +248,13 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
     cfg = GenConfig()
     vc = VisionConfig() if vision else None
     t0 = time.time()
-    llm = LLM(cfg, limit_mm_per_prompt={"image": max(5, n_images)}, max_model_len=4096, max_prefill=2048, device=device, vision=vc,
-              max_vision_rows=n_images * 1024 if vision else None, max_num_seqs=5)
+    a4_pages = bool(a4_pages and vision)
+    a4_hw = smart_resize(2339, 1654, vc.patch_size * vc.spatial_merge_size, vc.min_pixels, vc.max_pixels) if a4_pages else (0, 0)
+    a4_rows = (a4_hw[0] // vc.patch_size) * (a4_hw[1] // vc.patch_size) if a4_pages else 0      # patch rows of one A4 page
+    a4_prompt = 120 + 2 * n_images + n_images * (a4_rows // 4 if a4_pages else 0)
+    llm = LLM(cfg, limit_mm_per_prompt={"image": max(5, n_images)}, max_model_len=max(4096, a4_prompt + a4_tokens + 64),
+              max_prefill=max(2048, a4_prompt + 64), device=device, vision=vc,
+              max_vision_rows=max(n_images * 1024, n_images * a4_rows + 256) if vision else None, max_num_seqs=5)
     w = iter_synth_gen_weights(cfg, 0, device=f"cuda:{device}", bf16=True)
     if vision:
         w = itertools.chain(w, iter_synth_vision_weights(vc, 0, device=f"cuda:{device}", bf16=True))
@@ -339,6 +344,44 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
         torch.cuda.synchronize(device); bat_s = time.perf_counter() - a
         assert all(len(o.outputs[0].token_ids) == answer_tokens for o in outs)
     e2e = chain(llm) if chain is not None else None        # bench.py: query encode -> search -> page fetch -> generate
+    # ---- the reference's operating point (predict.py:112-123: five full pages, max_tokens=2048): A4 pages rasterised at 200 dpi
+    #      (1654 x 2339) through smart_resize at the processor's pixel limit, prefill of the ~6.4k-token prompt, 2048 answer tokens
+    a4 = None
+    if a4_pages:
+        pg = [torch.from_numpy(rng.integers(0, 256, size=(2339, 1654, 3), dtype=np.uint8)).to(f"cuda:{device}") for _ in range(n_images)]
+        short = [int(t) for t in rng.integers(1000, 50000, 60)] + [cfg.image_token_id, 198] * n_images + [int(t) for t in rng.integers(1000, 50000, 60)]
+        sp4 = SamplingParams(temperature=0.1, repetition_penalty=1.05, max_tokens=a4_tokens, stop_token_ids=())
+        ts, ds, T4 = [], [], 0
+        for rep in range(2):
+            torch.cuda.synchronize(device); a = time.perf_counter()
+            dev_pages, thw4 = process_pages_gpu(pg, vc, device)
+            pos3, ids4 = llm.prefill_images(short, dev_pages, thw4)
+            tok = llm.sample(sp4, 0)
+            torch.cuda.synchronize(device); b = time.perf_counter()
+            T4 = len(ids4)
+            n_dec = a4_tokens if rep == 1 else 8
+            llm._continue(tok, int(pos3.max()) + 1, n_dec, sp4, (), True)
+            torch.cuda.synchronize(device); c_ = time.perf_counter()
+            ts.append(b - a); ds.append((c_ - b) / max(1, n_dec - 1))
+        p4, d4 = ts[1], ds[1]
+        prs = [{"prompt_token_ids": short, "multi_modal_data": {"image": pg}}] * 5
+        torch.cuda.synchronize(device); a = time.perf_counter()
+        outs = llm.generate(prs, sp4)
+        torch.cuda.synchronize(device); bat4 = time.perf_counter() - a
+        assert all(len(o.outputs[0].token_ids) == a4_tokens for o in outs)
+        img_tok = a4_rows // (vc.spatial_merge_size ** 2)
+        # language-model prefill flops: weights 2 x stream x T + causal attention 2 x 2 x T^2 / 2 x hidden per layer
+        lm_flop = 2.0 * stream * T4 + 2.0 * cfg.num_hidden_layers * T4 * T4 * cfg.hidden_size
+        a4 = {"page": f"A4 @ 200 dpi, 1654 x 2339 u8 -> smart_resize {a4_hw[1]} x {a4_hw[0]} (max_pixels {vc.max_pixels})",
+              "image_tokens_per_page": img_tok, "patch_rows_per_page": a4_rows, "prompt_tokens": T4, "answer_tokens": a4_tokens,
+              "tower_plus_prefill_ms": round(p4 * 1e3, 1), "prefill_tokens_per_s": round(T4 / p4),
+              "language_model_prefill_tflop": round(lm_flop / 1e12, 1),
+              "tower_plus_prefill_tflops_lower_bound": round(lm_flop / p4 / 1e12, 1),
+              "decode_ms_per_token": round(d4 * 1e3, 3),
+              "queries_per_s": round(1.0 / (p4 + (a4_tokens - 1) * d4), 4),
+              "queries_per_s_five_together": round(5.0 / bat4, 4),
+              "what": "GPU image processing (Pillow-exact resize, rescale / normalise / patchify) -> tower -> prefill -> "
+                      f"{a4_tokens} captured decode + sample steps over a {T4}+ row cache; one query at a time and five together"}
     llm.close()
     T, p_s, d_s = len(ids), float(np.median(pre)), float(np.median(dec))
     return {
@@ -356,6 +399,7 @@ def bench_generate(n_images: int = 5, answer_tokens: int = 64, queries: int = 2,
         "queries_per_s_five_together": round(5.0 / bat_s, 3) if bat_s else None,
         "decode_ms_per_step_five_together": round((bat_s - 5 * p_s) / max(1, answer_tokens - 1) * 1e3, 3) if bat_s else None,
         "queries_per_s_at_2048_tokens": round(1.0 / (p_s + 2047 * d_s), 4),
+        "a4_pages": a4,
         "roofline": {"bound": "hbm", "kernel": "decode step (one captured hipGraph): vr::gemm_skinny_kernel (M = 1 weight streaming) + attention + norms + sampling",
                      "achieved": round(stream * 2 / d_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(stream * 2 / d_s / 8e12, 4),
                      "bytes_per_token": stream * 2}}
