@@ -70,7 +70,7 @@ struct vr_model_s {
     DevBuf w_hvit, w_xn, w_qkv, w_att, w_mlp, w_kv32, w_xkv, w_KV, w_ratt, w_rout, w_rln;
     DevBuf w_h, w_dxn, w_dqkv, w_datt, w_dact, w_part;   // w_part: split-K partial products [3][T][E] f32
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
-    DevBuf w_hp_hi, w_hp_lo, w_hp_qkv, w_hp_att, w_hp_gu, w_seqof;   // split-precision text path (hp_text.hip)
+    DevBuf w_hp_hi, w_hp_planes, w_hp_qkv, w_hp_att, w_hp_gu, w_seqof;   // split-precision text path (hp_text.hip)
     DevBuf w_hp_part;                                                 // its split-K planes for short batches (grown on demand)
     std::map<std::string, Tap> taps;
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
@@ -182,7 +182,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
                       &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
-                      &m->w_pix, &m->w_out, &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part})
+                      &m->w_pix, &m->w_out, &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part})
         b->free();
     delete m;
     return VR_OK;
@@ -459,8 +459,7 @@ static int alloc_workspace(vr_model_s* m) {
     VRCHK(m->w_out.alloc((size_t)c.max_seqs * E * 4));
     if (c.text_split_precision) {
         const int Kmax = std::max(E, m->Ip);
-        VRCHK(m->w_hp_hi.alloc((size_t)T * Kmax * 2));
-        VRCHK(m->w_hp_lo.alloc((size_t)T * Kmax * 2));
+        VRCHK(m->w_hp_hi.alloc((size_t)2 * T * Kmax * 2));       // [hi rows | lo rows]: the lo half starts right behind the batch's T hi rows
         VRCHK(m->w_hp_qkv.alloc((size_t)T * 3 * E * 4));
         VRCHK(m->w_hp_att.alloc((size_t)T * E * 4));
         VRCHK(m->w_hp_gu.alloc((size_t)T * pad128(2 * m->I) * 4));
@@ -761,22 +760,43 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
 }
 
 // ---- the decoder pass of a token-only batch at fp32-class precision (hp_text.hip) -----------------------------
-// out (+)= alpha * A W^T with A = hi + lo (bf16 halves in w_hp_hi / w_hp_lo, row pitch lda) and W = L (+ Llo):
+// out (+)= alpha * A W^T with A = hi + lo (bf16 halves a_hi / a_lo, row pitch lda: w_hp_hi holds [hi rows | lo rows]) and W = L (+ Llo):
 // A_hi W_hi, then A_lo W_hi and A_hi W_lo added in place by the residual epilogue of the same MFMA kernels.
-static int hp_gemm_tiles(vr_model_s* m, const Linear& L, const Linear& Llo, int lda, int T, float* out, int ldo, bool into_resid,
-                         float alpha, hipStream_t s) {
+static int hp_gemm_tiles(vr_model_s* m, const void* a_hi, const void* a_lo, const Linear& L, const Linear& Llo, int lda, int T, float* out,
+                         int ldo, bool into_resid, float alpha, hipStream_t s) {
+    // Round 4: the hi and lo halves of A are the ROWS of one GEMM — the lo rows are laid out right behind the T hi rows
+    // (run_decoder_hp) — so W_hi is streamed once, M = 2 T rows fill the 256-row tiles (T = 1300 for 64 queries ran 128 x 128
+    // tiles at 257 TF as two launches with a read-modify-write epilogue), and one fixed-order sum closes the planes
+    // [A_hi W_hi | A_lo W_hi | A_hi W_lo].  Falls back to the three in-place launches when the planes do not fit.
+    const size_t plane = (size_t)T * L.n_pad;
+    const int n_planes = Llo.has_w ? 3 : 2;
+    if ((const char*)a_lo == (const char*)a_hi + (size_t)T * lda * 2 && m->w_hp_planes.reserve((size_t)n_planes * plane * 4) == VR_OK) {
+        float* part = m->w_hp_planes.as<float>();
+        {
+            GemmArgs a = gemm_args(a_hi, lda, L, 2 * T, part, L.n_pad);
+            a.bias = nullptr;
+            HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s));
+        }
+        if (Llo.has_w) {
+            GemmArgs a = gemm_args(a_hi, lda, Llo, T, part + 2 * plane, L.n_pad);
+            a.bias = nullptr;
+            HIPCHK(launch_gemm(a, EPI_F32, GEMM_VARIANT_AUTO, s));
+        }
+        HIPCHK(launch_planes_sum(part, n_planes, plane, L.n_pad, T, std::min(L.n_pad, ldo), out, ldo, into_resid ? alpha : 1.0f, into_resid, s));
+        return VR_OK;
+    }
     {
-        GemmArgs a = gemm_args(m->w_hp_hi.p, lda, L, T, out, ldo);
+        GemmArgs a = gemm_args(a_hi, lda, L, T, out, ldo);
         if (into_resid) { a.resid = out; a.alpha = alpha; }
         HIPCHK(launch_gemm(a, into_resid ? EPI_RESID : EPI_F32, GEMM_VARIANT_AUTO, s));
     }
     {
-        GemmArgs a = gemm_args(m->w_hp_lo.p, lda, L, T, out, ldo);
+        GemmArgs a = gemm_args(a_lo, lda, L, T, out, ldo);
         a.resid = out; a.alpha = into_resid ? alpha : 1.0f;
         HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
     }
     if (Llo.has_w) {
-        GemmArgs a = gemm_args(m->w_hp_hi.p, lda, Llo, T, out, ldo);
+        GemmArgs a = gemm_args(a_hi, lda, Llo, T, out, ldo);
         a.resid = out; a.alpha = into_resid ? alpha : 1.0f;
         HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
     }
@@ -796,15 +816,15 @@ static int choose_stream_ksplit(int n_pad, int k_pad) {
     }
     return best;
 }
-static int hp_gemm_stream(vr_model_s* m, const Linear& L, const Linear& Llo, int lda, int T, float* out, int ldo, bool into_resid,
-                          float alpha, hipStream_t s) {
+static int hp_gemm_stream(vr_model_s* m, const void* a_hi, const void* a_lo, const Linear& L, const Linear& Llo, int lda, int T, float* out,
+                          int ldo, bool into_resid, float alpha, hipStream_t s) {
     const int ks = choose_stream_ksplit(L.n_pad, L.k_pad);
     const size_t plane = (size_t)T * L.n_pad;
     const int n_pass = Llo.has_w ? 3 : 2;
     if ((size_t)n_pass * ks * plane * 4 > m->w_hp_part.bytes) return fail(VR_ERR_CAPACITY, "split-K planes exceed the workspace");
     float* part = m->w_hp_part.as<float>();
     for (int pass = 0; pass < n_pass; ++pass) {
-        GemmArgs a = gemm_args(pass == 1 ? m->w_hp_lo.p : m->w_hp_hi.p, lda, pass == 2 ? Llo : L, T, part + (size_t)pass * ks * plane, L.n_pad);
+        GemmArgs a = gemm_args(pass == 1 ? a_lo : a_hi, lda, pass == 2 ? Llo : L, T, part + (size_t)pass * ks * plane, L.n_pad);
         a.bias = nullptr;
         a.ksplit = ks; a.split_stride = plane;
         HIPCHK(launch_gemm_skinny(a, s));
@@ -831,22 +851,24 @@ static int run_decoder_hp(vr_model_s* m, int T, int B, int max_len, hipStream_t 
     const int ld_gu = pad128(2 * I);
     HIPCHK(launch_seq_of(m->w_seq.as<int>(), B, m->w_seqof.as<int>(), s));
     const bool stream = hp_stream_ok(m, T);
+    void* const hi = m->w_hp_hi.p;
+    auto lo = [&](int lda) -> void* { return (char*)hi + (size_t)T * lda * 2; };     // the lo rows: right behind the T hi rows
     auto hp_gemm = [&](vr_model_s* mm, const Linear& L, const Linear& Llo, int lda, int TT, float* out, int ldo, bool into_resid,
                        float alpha, hipStream_t ss) -> int {
-        return stream ? hp_gemm_stream(mm, L, Llo, lda, TT, out, ldo, into_resid, alpha, ss)
-                      : hp_gemm_tiles(mm, L, Llo, lda, TT, out, ldo, into_resid, alpha, ss);
+        return stream ? hp_gemm_stream(mm, hi, lo(lda), L, Llo, lda, TT, out, ldo, into_resid, alpha, ss)
+                      : hp_gemm_tiles(mm, hi, lo(lda), L, Llo, lda, TT, out, ldo, into_resid, alpha, ss);
     };
     for (int l = 0; l < c.num_layers; ++l) {
         const DecLayer& L = m->layers[l];
-        HIPCHK(launch_rmsnorm_split(h, T, E, L.ln1.v.as<float>(), c.rms_norm_eps, m->w_hp_hi.p, m->w_hp_lo.p, s));
+        HIPCHK(launch_rmsnorm_split(h, T, E, L.ln1.v.as<float>(), c.rms_norm_eps, hi, lo(E), s));
         VRCHK(hp_gemm(m, L.qkv, L.qkv_lo, E, T, qkv, 3 * E, false, 1.0f, s));
         HIPCHK(launch_rope_f32(qkv, T, 3 * E, 2 * E, m->w_pos.as<int>(), m->rope.as<float>(), s));
         HIPCHK(launch_attn_f32(qkv, 3 * E, E, m->w_seqof.as<int>(), m->w_seq.as<int>(), T, c.num_heads, 1.0f / sqrtf(64.0f), att, s));
-        HIPCHK(launch_split_bf16(att, m->w_hp_hi.p, m->w_hp_lo.p, (size_t)T * E, s));
+        HIPCHK(launch_split_bf16(att, hi, lo(E), (size_t)T * E, s));
         VRCHK(hp_gemm(m, L.o, L.o_lo, E, T, h, E, true, c.residual_scale, s));
-        HIPCHK(launch_rmsnorm_split(h, T, E, L.ln2.v.as<float>(), c.rms_norm_eps, m->w_hp_hi.p, m->w_hp_lo.p, s));
+        HIPCHK(launch_rmsnorm_split(h, T, E, L.ln2.v.as<float>(), c.rms_norm_eps, hi, lo(E), s));
         VRCHK(hp_gemm(m, L.gu, L.gu_lo, E, T, gu, ld_gu, false, 1.0f, s));
-        HIPCHK(launch_swiglu_split(gu, T, ld_gu, I, Ip, m->w_hp_hi.p, m->w_hp_lo.p, s));
+        HIPCHK(launch_swiglu_split(gu, T, ld_gu, I, Ip, hi, lo(Ip), s));
         VRCHK(hp_gemm(m, L.down, L.down_lo, Ip, T, h, E, true, c.residual_scale, s));
         if (l == 0) VRCHK(tap_store(m, "dec_layer0", h, T, E, E, false, s));
     }
@@ -1107,7 +1129,7 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
                       &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out,
-                      &m->w_hp_hi, &m->w_hp_lo, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part}) {
+                      &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part}) {
         b->free();                                 // (a non-owning alias after the copy: just forget it)
     }
     m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)

@@ -115,8 +115,18 @@ static int persist_layers(vg_model_s* m, hipStream_t s) {
     return VR_OK;
 }
 // a barrier of the persistent kernel timed out (the workgroups were not all resident): everything after it is garbage
+// The kernel's abort flag and its barrier counters are sticky: leave the persistent path for good — the step that timed out
+// is reported as failed (its logits are garbage), every later step runs as separate launches (p_grid = 0) on clean state.
 static int persist_check(vg_model_s* m) {
-    if (m->p_abort && *m->p_abort) return fail(VR_ERR_HIP, "the decode kernel's grid barrier timed out (its workgroups must all be resident: one per CU)");
+    if (m->p_abort && *m->p_abort) {
+        *m->p_abort = 0;
+        m->p_grid = 0;
+        if (m->p_sync.p) (void)hipMemset(m->p_sync.p, 0, 128 * 8);
+        if (m->p_ss.p) (void)hipMemset(m->p_ss.p, 0, 16 * 4);
+        return fail(VR_ERR_HIP, "the decode kernel's grid barrier timed out (its workgroups must all be resident: one per CU — "
+                                "another kernel was running on the device?); this step's result is invalid, the model has fallen "
+                                "back to separate launches for the steps that follow: prefill again and continue");
+    }
     return VR_OK;
 }
 
