@@ -1031,7 +1031,17 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
 #ifndef VR_DEC_O_GLDS
 #define VR_DEC_O_GLDS 0
 #endif
+#ifndef VR_DEC_O_NOSPLIT
+#define VR_DEC_O_NOSPLIT 0
+#endif
     auto proj = [&](const void* A, int lda, const Linear& L, bool is_o = false) -> int {
+        if (VR_DEC_O_NOSPLIT && is_o && ks > 1 && proj_variant == GEMM_VARIANT_192W) {
+            // A/B knob: the o projection (K = E: 36 K-steps) WITHOUT split-K on the 256 x 192 tile — 108 workgroups on 256 CUs,
+            // but no fp32 planes: the residual epilogue adds in place and the RMSNorm that follows is the plain one
+            GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;
+            HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_192W, s));
+            return VR_OK;
+        }
         if (VR_DEC_O_GLDS && is_o && !m->taps_on) {
             // A/B knob: the o projection (K = E: the smaller of the two) on 128 x 128 tiles straight into the residual stream
             GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;
