@@ -187,6 +187,28 @@ def test_attention(hd, heads, lens, causal):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("lens,causal", [([68] * 7, True), ([68, 13, 80, 1, 16, 17, 79, 33], True), ([68, 5, 80, 48], False)])
+def test_attention_short_sequences_one_wave_each(lens, causal):
+    """attention_small.hip: self-attention of packed sequences of at most 80 tokens (head_dim 64, cu_q IS cu_kv — the
+    decoder over a page's 68 tokens), one wave per (sequence, head), against the fp32 reference and against the tiled
+    kernel (which the same call takes when the two offset arrays are different buffers)."""
+    hd, heads = 64, 5
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    T, W = int(cu[-1]), heads * hd
+    qkv = _bf(_rand((T, 3 * W), 30, 1.0))
+    d, cud = qkv.to(DEV), cu.to(DEV)
+    scale = hd ** -0.5
+    small = op_attention(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], cud, cud, heads, hd, max(lens), causal, False, scale, T).float().cpu()
+    tiled = op_attention(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], cud, cud.clone(), heads, hd, max(lens), causal, False, scale, T).float().cpu()
+    for b in range(len(lens)):
+        lo, hi = int(cu[b]), int(cu[b + 1])
+        for h in range(heads):
+            ref = _ref_attn(qkv[lo:hi, h * hd:(h + 1) * hd], qkv[lo:hi, W + h * hd: W + (h + 1) * hd],
+                            qkv[lo:hi, 2 * W + h * hd: 2 * W + (h + 1) * hd], causal, scale)
+            np.testing.assert_allclose(small[lo:hi, h * hd:(h + 1) * hd].numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(small.numpy(), tiled.numpy(), rtol=2e-2, atol=1e-2)
+
+
 def test_attention_segments_head_dim_128():
     """The vision tower's form: head_dim-128 slots, bidirectional attention inside ragged row segments (windows of up
     to 64 rows, whole images), own q rows per segment, a scale that is not 1/sqrt(128)."""

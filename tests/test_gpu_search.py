@@ -336,7 +336,7 @@ def test_exact_pass_alone_matches_oracle(nd, nq, dim, k):
     st = ix.search_stats()
     kk = min(k, nd)
     if nd > k + 24:
-        assert st["flagged"] == nq and (st["exact_pass"] == nq if nd > 8192 else st["band_pass"] == nq), st
+        assert st["flagged"] == nq and (st["exact_pass"] == nq if nd > 8192 else st["band_pass"] == nq), st        # (<= 8192 rows: a band-pass round per query)
     _assert_ids_equal_fp64(ids[:, :kk], sc[:, :kk], C, Q, kk)
     if kk < k:
         assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()

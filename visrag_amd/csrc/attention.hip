@@ -68,10 +68,18 @@ static hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifndef VR_ATTN_SMALL
+#define VR_ATTN_SMALL 1
+#endif
+bool attention_small_ok(const AttnArgs& a);
+hipError_t launch_attention_small(const AttnArgs& a, hipStream_t s);
+
 hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (a_in.B <= 0 || a_in.max_q <= 0) return hipSuccess;
     if ((a_in.ldq | a_in.ldk | a_in.ldv) % 8 || a_in.ldo % 4) return hipErrorInvalidValue;
     const AttnArgs& a = a_in;
+    // self-attention of short packed sequences (the decoder over a page's 68 tokens): a wave per (sequence, head)
+    if (VR_ATTN_SMALL && attention_small_ok(a)) return launch_attention_small(a, s);
     // q-fragments per wave: 2 (32 rows) for long sequences; PIPE 0 (single slot, no pipeline prologue) is the
     // fastest form for the one- or two-tile sequences of the decoder (68-token pages: 13.8 vs 15.7 us)
     const bool big = a.max_q > 64;
