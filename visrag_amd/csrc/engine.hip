@@ -1173,7 +1173,7 @@ extern "C" int vr_model_get_profile(vr_model_t m, int32_t cls, double* total_ms,
 }
 
 // --------------------------------------------------------------------------------- index ---
-constexpr int CERT_WORDS = 32, CERT_FLAG = 2, CERT_FLAG2 = 3, CERT_STATS = 4, CERT_NSTATS = 6;
+constexpr int CERT_WORDS = 32, CERT_FLAG = 2, CERT_FLAG2 = 3, CERT_STATS = 4, CERT_NSTATS = 6;   // (the two flag counters are consecutive: cleared together)
 struct vr_index_s {
     int device = 0, dim = 0;
     int64_t cap = 0, n = 0;
@@ -1183,7 +1183,7 @@ struct vr_index_s {
     // certification state (search_common.h), 32 words: f32 [0] largest row norm, [1] largest bf16 rounding residual of a row;
     // int [2] flag count, [3] second-level flag count (exact fp32 pass); u32 [4..9] query counters {certified at once, after
     // extended re-scoring, flagged, uncertified mode, candidates gathered a second time, of the flagged: exact fp32 pass}
-    DevBuf cert, flags, flagq;        // flags: int flag_list[fcap] | int flag2_list[fcap] | f32 flag_tau[fcap] | u32 flag_top[fcap]; flagq: bf16 [fcap][dim]
+    DevBuf cert, flags, flagq;        // flags: int flag_list[fcap] | int flag2_list[fcap] | f32 flag_tau[fcap]; flagq: bf16 [fcap][dim]
     int64_t fcap = 0;
     float eps_rel = -2.f;             // -2: the rigorous data-dependent default; >= 0: the caller's eps_rel |q| max|d|; else off
     // per-stage HIP events (vr_index_set_search_profile): convert | thresholds | sweep | merge | exact pass
@@ -1349,7 +1349,7 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
         }
     } else {
         if (ix->fcap < nqp) {
-            VRCHK(ix->flags.alloc((size_t)nqp * 16));
+            VRCHK(ix->flags.alloc((size_t)nqp * 12));
             VRCHK(ix->flagq.alloc((size_t)(nqp + 256) * dim * 2));     // (+ one tile: the GEMM's last row tile may start anywhere)
             ix->fcap = nqp;
         }
@@ -1376,7 +1376,6 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
             a.flag_count = ix->cert.as<int>() + CERT_FLAG; a.flag_list = ix->flags.as<int>();
             a.flag2_count = ix->cert.as<int>() + CERT_FLAG2; a.flag2_list = ix->flags.as<int>() + ix->fcap;
             a.flag_tau = ix->flags.as<float>() + 2 * ix->fcap; a.flag_q = ix->flagq.p;
-            a.flag_top = ix->flags.as<unsigned>() + 3 * ix->fcap;
             a.stats = ix->cert.as<unsigned>() + CERT_STATS;
             if (keys_out) { a.out_keys = ok + (size_t)q0 * k; a.id_offset = id_offset; }
             else { a.out_scores = os + (size_t)q0 * k; a.out_ids = oi + (size_t)q0 * k; }

@@ -237,7 +237,6 @@ struct SearchArgs {
     const float* dmax;               // device floats: [0] largest row norm |d|, [1] largest bf16 rounding residual |d - bf16(d)|
     int* flag_count; int* flag_list; // queries whose top-k could not be certified: the band pass (search_band.hip) redoes them
     float* flag_tau;                 // [slot] the flagged query's tau = s_k - eps (-inf: unknown)
-    unsigned* flag_top;              // [slot] row id of its best candidate (0xffffffff: none): the band pass groups neighbours
     void* flag_q;                    // bf16 [slots][dim]: the flagged queries' bf16 rows, compacted (the band pass's GEMM operand)
     int* flag2_count; int* flag2_list;   // flagged queries whose band holds too many rows: the exact fp32 pass redoes them
     unsigned* stats;                 // [0] certified at once [1] after extended re-scoring [2] flagged [3] uncertified mode

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void bigk_select_kernel(SearchArgs p, const fl
         }
         if (tid == 0 && p.stats) atomicAdd(&p.stats[what], 1u);
         __syncthreads();
-        flag_query(p, q, what == 2, tau, &sh_rank, ~(uint32_t)keys[0]);
+        flag_query(p, q, what == 2, tau, &sh_rank);
     } else if (!exact && tid == 0 && p.stats) {
         atomicAdd(&p.stats[3], 1u);
     }

@@ -159,13 +159,12 @@ __device__ __forceinline__ float query_eps(const SearchArgs& p, const f32x4 (&qv
 
 // a query that could not be certified goes on the flag list with its tau and its bf16 row (the band pass's GEMM operand);
 // called by the whole workgroup with `flagged` workgroup-uniform; sh_pos: LDS scratch
-__device__ __forceinline__ void flag_query(const SearchArgs& p, int q, bool flagged, float tau, int* sh_pos, uint32_t top_row) {
+__device__ __forceinline__ void flag_query(const SearchArgs& p, int q, bool flagged, float tau, int* sh_pos) {
     if (!flagged || !p.flag_count) return;
     if (threadIdx.x == 0) {
         const int pos = atomicAdd(p.flag_count, 1);
         p.flag_list[pos] = q;
         if (p.flag_tau) p.flag_tau[pos] = tau;
-        if (p.flag_top) p.flag_top[pos] = top_row;
         *sh_pos = pos;
     }
     __syncthreads();
@@ -273,7 +272,7 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
         }
     }
     // (coverB / dropB / tau / x are workgroup-uniform: every thread evaluates the same predicate)
-    flag_query(p, q, certify && !(below(coverB, tau) && below(dropB, tau)), tau, sh_x, ~(uint32_t)cand[0]);
+    flag_query(p, q, certify && !(below(coverB, tau) && below(dropB, tau)), tau, sh_x);
 }
 
 }  // namespace vr
