@@ -154,7 +154,9 @@ def main():
     pipelined = None
     if args.pipelined or not args.no_extras:
         enc2 = enc.clone()
-        slots = [(enc, torch.cuda.Stream(device=dev), out), (enc2, torch.cuda.Stream(device=dev), torch.empty_like(out))]
+        from visrag_amd.engine import overlapping_streams
+        sa, sb = overlapping_streams(dev, 2)            # (two pool streams can share a hardware queue: probed)
+        slots = [(enc, sa, out), (enc2, sb, torch.empty_like(out))]
 
         def pstep(i):
             e, st, o = slots[i & 1]

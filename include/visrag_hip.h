@@ -236,6 +236,13 @@ int vr_topk_merge_keys(int device_id, const uint64_t* keys, int32_t n_parts, int
  * config 3 needs 100 000 distinct pages; there is no dataset on the box (BASELINE.json: "data": synthetic). */
 int vr_synth_pages(int device_id, uint8_t* out, int32_t n, int32_t size, int64_t seed, int64_t first, void* stream);
 
+/* ---- streams (caller support; no reference counterpart) ------------------------------------ */
+/* *overlap = 1 when kernels on the two streams run SIDE BY SIDE, 0 when the runtime put the streams on one hardware
+ * queue (kernels of one wait for the other's).  Probed with two 400 us one-thread kernels, three rounds (~2.5 ms);
+ * both streams are synchronised.  A caller that keeps two vr_model_clone workspaces in flight picks its stream pair
+ * with this (visrag_amd/engine.py::overlapping_streams): a pair on one queue runs at the single-stream rate. */
+int vr_streams_overlap(int device_id, void* stream_a, void* stream_b, int32_t* overlap);
+
 /* ---- host pre-processing moved to the GPU ------------------- */
 /* Bicubic resize of an 8-bit RGB (HWC) image, bit-exact with Pillow's
  * Image.resize((out_w, out_h), Image.Resampling.BICUBIC) — the resize of slice_image /

@@ -241,3 +241,15 @@ def test_attention_spiked_scores():
                        hd ** -0.5, L).float().cpu()
     ref = _ref_attn(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], False, hd ** -0.5)
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+
+
+def test_stream_pairs_for_two_batches_in_flight_overlap():
+    """engine.overlapping_streams: the pair of streams DRModelForInference keeps two batches in flight on must not share a
+    hardware queue (vr_streams_overlap probes with two spin kernels); a stream never overlaps itself."""
+    from visrag_amd.engine import overlapping_streams, streams_overlap
+    sa, sb = overlapping_streams(0, 2)
+    assert sa.cuda_stream != sb.cuda_stream
+    assert streams_overlap(sa, sb)
+    assert not streams_overlap(sa, sa)
+    three = overlapping_streams(0, 3)
+    assert len({s.cuda_stream for s in three}) == 3

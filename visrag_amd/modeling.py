@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .config import VisRAGRetConfig, full_config
-from .engine import HipEncoder
+from .engine import HipEncoder, overlapping_streams
 from .preprocess import PreparedItem, prepare_batch
 
 
@@ -93,8 +93,9 @@ class DRModelForInference:
         depth = max(1, int(depth))
         enc = self.encoder
         dev = torch.device(f"cuda:{enc.device}")
+        # (streams that really overlap: two pool streams can share a hardware queue, engine.py::overlapping_streams)
         self._slots = [(enc, None)] if depth == 1 else \
-            [(enc if j == 0 else enc.clone(), torch.cuda.Stream(device=dev)) for j in range(depth)]
+            [(enc if j == 0 else enc.clone(), st) for j, st in enumerate(overlapping_streams(dev, depth))]
         self._rr = 0
 
     def eval(self):
