@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from PIL import Image
 from visrag_amd.config import full_config
-from visrag_amd.engine import HipEncoder
+from visrag_amd.engine import HipEncoder, overlapping_streams
 from visrag_amd.preprocess import prepare_batch
 from visrag_amd.synth import iter_synth_weights, synth_pages
 from visrag_amd.tokenizer import StandInTokenizer
@@ -19,7 +19,7 @@ pages = synth_pages(B, size=448, seed=0)
 items = prepare_batch([""] * B, [Image.fromarray(p) for p in pages], tok, cfg, 2048)
 dev = [torch.from_numpy(p).cuda() for p in pages]
 outs = [torch.empty((B, cfg.hidden_size), dtype=torch.float32, device="cuda") for _ in range(N)]
-streams = [torch.cuda.Stream() for _ in range(N)]
+streams = overlapping_streams(0, N)       # (pool streams can share a hardware queue: probed)
 def run(n, two):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n):
