@@ -367,6 +367,26 @@ def test_random_index_is_certified_without_the_exact_pass():
     assert int(bad.any(dim=1).sum()) <= 3 and (not bool(bad.any()) or float((rv - torch.gather(Q.double() @ C.double().T, 1, ids)).abs()[bad].max()) < 1e-7)
 
 
+@pytest.mark.parametrize("nd,nq,dim,k", [(2000, 1000, 2304, 10), (600, 300, 512, 10), (5000, 257, 1024, 10), (3000, 64, 2304, 16),
+                                          (1500, 400, 256, 1), (7000, 1000, 768, 26), (2000, 130, 2304, 10), (900, 1000, 128, 10)])
+def test_small_shards_are_searched_from_compacted_lists(nd, nq, dim, k):
+    """A shard too small for the pre-pass threshold (fewer than 64 row tiles: the per-file searches of
+    distributed_parallel_retrieve over small max_inmem_docs shards, an 8-way shard of a small corpus): every row enters a
+    half-list and every half-list is compacted.  What compaction dropped is bounded per list (search256.hip: the largest
+    KP-th best of a compacted half-list), not by the global KP-th best — which lies inside the error band of the k-th
+    and sent four queries in five through the band pass until round 4.  ids == fp64 either way; the first case also
+    watches the flagged share."""
+    C, Q = _unit(nd, dim, 71), _unit(nq, dim, 72)
+    ix = HipIndex(dim, nd); ix.add(C)
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    assert st["uncertified"] == 0, st
+    if (nd, nq, dim) == (2000, 1000, 2304):
+        assert st["flagged"] < nq // 2, st
+
+
 @pytest.mark.parametrize("nd,nq,dim,k", [(20000, 300, 512, 10), (3000, 7, 256, 26), (20000, 64, 512, 100), (5, 3, 64, 10)])
 def test_search_keys_and_merge_keys(nd, nq, dim, k):
     """The packed exchange format (vr_index_search_keys / vr_topk_merge_keys): one 64-bit word per result, the

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     __shared__ uint64_t cand[64], exact_s[64];
     __shared__ uint64_t thr_s;
     __shared__ int n_s, x_s, comp_s;
+    __shared__ unsigned drop_s;
     __shared__ float tau_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
@@ -269,11 +270,16 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
 
     uint64_t m = KEY_NONE;
     int comp = 0;
-    if (tid == 0) comp_s = 0;
+    unsigned drop = 0u;                                  // orderable score: the best KP-th entry of a compacted half-list
+    if (tid == 0) { comp_s = 0; drop_s = 0u; }
     for (int l = tid; l < lists; l += 256) {
         const int cw = cnts[l];
         const int c = cw & 0xFF;
         comp |= cw >> 8;
+        // a compacted half-list keeps its best KP sorted in slots 0 .. KP-1 (later rows are appended behind them): slot KP-1 is
+        // the threshold that compaction raised — what it dropped, and what the raised threshold kept out of this list and its
+        // partner half afterwards, scores no higher.  (A half-list flagged for its partner's compaction: any entry of it, looser.)
+        if ((cw >> 8) && c >= KP) drop = max(drop, (unsigned)(keys[(size_t)l * HL_CAP + KP - 1] >> 32));
         const u64x2* row = reinterpret_cast<const u64x2*>(keys + (size_t)l * HL_CAP);
         for (int e = 0; e < c; e += 4) {
             const u64x2 a = row[e >> 1], b2 = row[(e >> 1) + 1];
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     lm[tid] = m;
     __syncthreads();
     if (comp) atomicOr(&comp_s, 1);
+    if (drop) atomicMax(&drop_s, drop);
     if (wave == 0) {
         uint64_t v = lm[lane];
 #pragma unroll
@@ -339,10 +346,17 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     // what the re-scoring does not see (search_common.h: certify_tail):
     //   list entries outside `cand`: below the gather bound, or (more than 64 gathered) below cand[63];
     //   rows that never reached a list: below the sweep's starting threshold — or, where a half-list was compacted
-    //   (its chunk's threshold rose to that list's KP-th best, itself <= the global KP-th best), below cand[KP - 1]
+    //   (its chunk's threshold rose to that list's KP-th best), below the largest such KP-th best (drop_s) and below the
+    //   global KP-th best cand[KP - 1]: two valid bounds, the smaller one is taken.  (Until round 4 only the global one:
+    //   on a shard too small for the pre-pass EVERY half-list is compacted, the global KP-th best lies inside the error band
+    //   of the k-th, and four queries in five went to the band pass.)
     const float coverB = n > 64 ? key_score(cand[63]) : (thr == KEY_NONE ? -INFINITY : key_score(thr));
     float dropB = p.thr_used ? p.thr_used[q] : -INFINITY;
-    if (comp_s && cand[KP - 1] != KEY_NONE) dropB = fmaxf(dropB, key_score(cand[KP - 1]));
+    if (comp_s && cand[KP - 1] != KEY_NONE) {
+        float b = key_score(cand[KP - 1]);
+        if (drop_s) b = fminf(b, orderable_f32(drop_s));
+        dropB = fmaxf(dropB, b);
+    }
     certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
                      [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); }, surv, exact_w);
 }
