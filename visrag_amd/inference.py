@@ -84,20 +84,23 @@ def _prefetched_batches(dataset, batch_size: int, num_workers: int, prefetch: in
     q: "queue.Queue" = queue.Queue(maxsize=max(1, prefetch))
     stop = threading.Event()
 
+    def put(x) -> bool:                  # False: the consumer is gone (never blocks on a queue nobody reads)
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def work():
         try:
             for b in _batches((_to_array(ex, to_u8) for ex in dataset), batch_size):
-                while not stop.is_set():
-                    try:
-                        q.put(b, timeout=0.1)
-                        break
-                    except queue.Full:
-                        continue
-                if stop.is_set():
+                if not put(b):
                     return
-            q.put(_END)
+            put(_END)
         except BaseException as e:       # surfaces in the consumer
-            q.put(e)
+            put(e)
 
     t = threading.Thread(target=work, name="visrag-loader", daemon=True)
     t.start()

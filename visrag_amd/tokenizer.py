@@ -134,7 +134,7 @@ class SentencePieceTokenizer:
     def im_end_id(self) -> int: return self.sp_model.piece_to_id(self.im_end)
 
     def encode(self, text: str) -> List[int]:
-        ids: List[int] = [self.bos_id] if self.add_bos_token else []
+        ids: List[int] = [self.bos_id] if self.add_bos_token and self.bos_id >= 0 else []
         for piece in self._split.split(text):
             if not piece:
                 continue
@@ -142,7 +142,7 @@ class SentencePieceTokenizer:
                 ids.append(self._special[piece])
             else:
                 ids.extend(self.sp_model.encode(piece))
-        if self.add_eos_token:
+        if self.add_eos_token and self.eos_id >= 0:
             ids.append(self.eos_id)
         return ids
 
