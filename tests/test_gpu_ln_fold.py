@@ -1,0 +1,172 @@
+"""-m gpu, OFF unless VISRAG_TEST_LN_FOLD=1: the experimental folding of the ViT blocks' LayerNorms into the GEMMs around
+them (include/visrag_hip.h: vr_op_gemm_ln; VR_VIT_LN_FOLD=1 at vr_model_create).  Written in round 4 without a GPU at
+hand — the default path does not run any of this, and these tests are skipped until the code has been run once:
+
+  * vr_op_ln_fold_weights against torch (W' = bf16(gamma o W), c1, c2);
+  * the residual GEMM with the extra outputs: fp32 result BIT-IDENTICAL to the default residual kernel, bf16 copy ==
+    bf16(result), partial sums == torch's over the same column ranges;
+  * vr_op_ln_fold_stats against torch;
+  * the consuming GEMMs (plain and GELU) against LayerNorm -> default GEMM on the same rows;
+  * the encoder with the knob against the encoder without, full dims (torch fp32 reference of the op: nn.LayerNorm)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from visrag_amd import _lib
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("VISRAG_TEST_LN_FOLD") != "1",
+                                                  reason="experimental LayerNorm folding: set VISRAG_TEST_LN_FOLD=1")]
+
+from gpu_util import P, op_gemm, op_norm, pad_rows  # noqa: E402
+
+D = 1152
+
+
+def _fold_weights(W, gamma, beta, bias):
+    lib = _lib.load()
+    n_pad, ldw = W.shape
+    W2 = torch.empty_like(W)
+    c1 = torch.empty(n_pad, device="cuda")
+    c2 = torch.empty(n_pad, device="cuda")
+    _lib.check(lib.vr_op_ln_fold_weights(0, P(W), n_pad, gamma.numel(), ldw, P(gamma), P(beta), P(bias), P(W2), P(c1), P(c2), None))
+    torch.cuda.synchronize()
+    return W2, c1, c2
+
+
+def test_fold_weights_match_torch():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    n_pad, k, ldw = 384, 1088, 1152
+    W = torch.zeros((n_pad, ldw), device="cuda")
+    W[:300, :k] = torch.randn((300, k), generator=g, device="cuda") * 0.05
+    W = W.to(torch.bfloat16)
+    gamma = 1 + 0.3 * torch.randn(k, generator=g, device="cuda")
+    beta = 0.2 * torch.randn(k, generator=g, device="cuda")
+    bias = torch.randn(n_pad, generator=g, device="cuda")
+    W2, c1, c2 = _fold_weights(W, gamma, beta, bias)
+    ref = (W[:, :k].float() * gamma).to(torch.bfloat16)
+    assert torch.equal(W2[:, :k], ref) and torch.equal(W2[:, k:], W[:, k:])
+    torch.testing.assert_close(c1, ref.double().sum(1).float(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(c2, (bias.double() + (W[:, :k].double() * beta.double()).sum(1)).float(), atol=1e-5, rtol=1e-5)
+
+
+def _producer(A, W, bias, resid):
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    Ap, out = pad_rows(A), pad_rows(resid.clone())
+    xb = torch.zeros((Ap.shape[0], N), dtype=torch.bfloat16, device="cuda")
+    parts = 2 * N // 192
+    part = torch.zeros((Ap.shape[0], parts, 2), device="cuda")
+    _lib.check(lib.vr_op_gemm_ln(0, P(Ap), K, P(W), K, M, N, K, 3, P(bias), P(out), P(out), N, P(xb), N, P(part), parts, None, None, None))
+    torch.cuda.synchronize()
+    return out[:M], xb[:M], part[:M]
+
+
+@pytest.mark.parametrize("M,K", [(600, 1152), (2048, 4352), (257, 1152)])
+def test_residual_gemm_with_bf16_copy_and_partial_sums(M, K):
+    g = torch.Generator(device="cuda").manual_seed(M)
+    A = (torch.randn((M, K), generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    W = (torch.randn((D, K), generator=g, device="cuda") * 0.03).to(torch.bfloat16)
+    bias = torch.randn(D, generator=g, device="cuda") * 0.1
+    resid = torch.randn((M, D), generator=g, device="cuda") * 2 + 0.3
+    out, xb, part = _producer(A, W, bias, resid)
+    ref = op_gemm(A, W, 3, bias=bias, resid=resid, out_dtype=torch.float32, variant=13)       # the default residual kernel
+    assert torch.equal(out, ref)
+    assert torch.equal(xb, out.to(torch.bfloat16))
+    cols = out.double().view(M, D // 96, 96)
+    torch.testing.assert_close(part[..., 0].double(), cols.sum(2), atol=2e-3, rtol=1e-5)
+    torch.testing.assert_close(part[..., 1].double(), (cols * cols).sum(2), atol=2e-2, rtol=1e-5)
+
+
+def _stats(part, dim, eps):
+    lib = _lib.load()
+    rows, parts, _ = part.shape
+    ab = torch.empty((rows, 2), device="cuda")
+    _lib.check(lib.vr_op_ln_fold_stats(0, P(part.contiguous()), parts, rows, dim, float(eps), P(ab), None))
+    torch.cuda.synchronize()
+    return ab
+
+
+def test_fold_stats_match_torch():
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((777, D), generator=g, device="cuda") * 3 + 1.5
+    cols = x.double().view(777, 12, 96)
+    part = torch.stack([cols.sum(2), (cols * cols).sum(2)], dim=2).float()
+    ab = _stats(part, D, 1e-6)
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-6)
+    torch.testing.assert_close(ab[:, 0].double(), rstd, atol=0, rtol=2e-5)
+    torch.testing.assert_close(ab[:, 1].double(), -mean * rstd, atol=1e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("epi,N,M", [(0, 3456, 1000), (1, 4352, 1000), (1, 4352, 300), (0, 3456, 2048)])
+def test_consuming_gemm_equals_layernorm_then_gemm(epi, N, M):
+    """rows with outlier channels and a mean of the size of their spread, like a ViT's residual stream"""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(10 * epi + M)
+    x = torch.randn((M, D), generator=g, device="cuda") * 1.5 + 0.4
+    x[:, 7] *= 30
+    x[:, 500] -= 40
+    W = torch.zeros((N, D), device="cuda")
+    n_real = N - 48 if epi == 1 else N
+    W[:n_real] = torch.randn((n_real, D), generator=g, device="cuda") * 0.03
+    W = W.to(torch.bfloat16)
+    gamma = 1 + 0.2 * torch.randn(D, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(D, generator=g, device="cuda")
+    bias = torch.zeros(N, device="cuda")
+    bias[:n_real] = torch.randn(n_real, generator=g, device="cuda") * 0.1
+    # the default route: LayerNorm launch -> GEMM
+    xn = op_norm(0, x, gamma, beta, 1e-6)
+    want = op_gemm(xn, W, epi, bias=bias, variant=12).float()
+    # folded: raw bf16 rows, scaled weights, per-row (rstd, -mean rstd)
+    W2, c1, c2 = _fold_weights(W, gamma, beta, bias)
+    cols = x.double().view(M, 12, 96)
+    ab = _stats(torch.stack([cols.sum(2), (cols * cols).sum(2)], dim=2).float(), D, 1e-6)
+    xb, abp = pad_rows(x.to(torch.bfloat16)), pad_rows(ab)
+    out = torch.zeros((xb.shape[0], N), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.vr_op_gemm_ln(0, P(xb), D, P(W2), D, M, N, D, epi, P(c2), None, P(out), N, None, 0, None, 0, P(abp), P(c1), None))
+    torch.cuda.synchronize()
+    got = out[:M].float()
+    # fp64 reference of the op (torch LayerNorm -> linear [-> exact GELU])
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-6) @ W.double().T + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    scale = float(ref.abs().max())
+    err_default, err_fold = float((want.double() - ref).abs().max()), float((got.double() - ref).abs().max())
+    assert err_fold < max(2.0 * err_default, 4e-3 * scale), (err_fold, err_default, scale)
+    assert float((got[:, n_real:]).abs().max()) == 0.0 if n_real < N else True
+
+
+def test_encoder_with_folded_layernorms_equals_encoder_without():
+    from PIL import Image
+    from visrag_amd.config import full_config
+    from visrag_amd.engine import HipEncoder
+    from visrag_amd.preprocess import prepare_batch
+    from visrag_amd.synth import iter_synth_weights, synth_pages
+    from visrag_amd.tokenizer import StandInTokenizer
+    cfg = full_config()
+    tok = StandInTokenizer(cfg.vocab_size)
+    pages = [Image.fromarray(p) for p in synth_pages(6, size=448, seed=0)]
+    pages.append(Image.fromarray(synth_pages(1, size=700, seed=3)[0][:500, :700]))          # sliced page: several grids
+    items = prepare_batch([""] * len(pages), pages, tok, cfg, 2048)
+    outs = []
+    for knob in ("0", "1"):
+        os.environ["VR_VIT_LN_FOLD"] = knob
+        try:
+            enc = HipEncoder(cfg, max_images=16, max_tokens=4096, max_seqs=16)
+        finally:
+            os.environ.pop("VR_VIT_LN_FOLD", None)
+        enc.load_state_dict(iter_synth_weights(cfg, 0, device="cuda"))
+        enc.set_taps(True)
+        outs.append((enc.encode_items(items).cpu().numpy(), enc.tap("vit_out", 1024, cfg.vit_dim)))
+        enc.close()
+    (p0, v0), (p1, v1) = outs
+    assert np.isfinite(p1).all()
+    cos = (p0 * p1).sum(1)
+    assert cos.min() > 1 - 2e-4, cos
+    vcos = (v0 * v1).sum(1) / (np.linalg.norm(v0, axis=1) * np.linalg.norm(v1, axis=1))
+    assert vcos.min() > 1 - 1e-3, vcos.min()
+    assert not np.array_equal(p0, p1), "the knob did nothing"

@@ -65,338 +65,40 @@ constexpr unsigned W_OOB = 0x80000000u;            // per-lane offset beyond the
 constexpr int W_STAGING = 4096;                            // epilogue staging per wave: one piece of 32 rows x 64 bf16
 constexpr int W_SMEM_BYTES = 2 * W_STAGE + 4 * W_STAGING;  // two stages + staging = 144 KiB
 
-template <int EPI, bool PLAIN, int NJ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256w_bf16_kernel(GemmArgs p) {
-    static_assert(NJ == 8 || (NJ == 6 && !PLAIN), "wave tile 128 x 128 or 128 x 96");
-    constexpr int BN = 32 * NJ;                 // tile columns
-    constexpr int NS = 8 * NJ;                  // MFMAs per phase (slots)
-    constexpr int NR = 8 + NJ;                  // fragment reads per k-half = LDS-DMA loads per K-step and wave
-    constexpr int DS = NJ == 8 ? 5 : 4;         // one load per DS slots
-    constexpr int SB1 = NS * 5 / 8;             // slot of the phase-1 barrier (the k-half-1 reads end at slot 2 NR - 2)
-    constexpr int D1 = (NS - 1 - (SB1 + 2)) / DS + 1;   // loads issued in phase 1 (slots SB1 + 2, + DS, ...)
-    constexpr int SB2 = NJ;                     // slot of the phase-2 barrier
-    constexpr int NF = NJ / 2;                  // fragments per epilogue piece: 64 or 48 columns
-    static_assert(SB2 + 3 + DS * (NR - D1 - 1) < NS && SB2 + 2 + 2 * (NR - 1) < NS && 2 * NR - 2 < SB1, "schedule fits");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef VR_W_TIMING                   // tile anatomy (tools/w_anatomy.py, tagged builds only, one tile per workgroup)
-    const unsigned long long tm0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long tm1 = 0, tm2 = 0, cy1 = 0, cy2 = 0;
-#endif
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + G256_BM - 1) / G256_BM;
-    const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    const int total = tiles_m * tiles_n * ks;
-    const int Ks = p.K / ks;
-    const int nk = Ks / GEMM_BK;
+constexpr int W_LN_AB = 1024;                              // LNF = 2: a wave's 128 rows x (a, b), fetched by LDS-DMA at tile start
+constexpr int W_SMEM_BYTES_LN = W_SMEM_BYTES + 4 * W_LN_AB;
 
-    const int my_first = xcd_remap(blockIdx.x, total);
-    // tile index -> (m0, n0, split); grouped rasterisation as in gemm256_bf16_kernel
-    const int GM = p.raster_gm > 0 ? p.raster_gm : 1;
-    auto coords = [&](int tt, int& m0, int& n0, int& split) {
-        split = tt / (tiles_m * tiles_n);
-        const int t = tt - split * (tiles_m * tiles_n);
-        const int gsz = GM * tiles_n;
-        const int g = t / gsz, r = t % gsz;
-        const int gm = min(GM, tiles_m - g * GM);
-        m0 = __builtin_amdgcn_readfirstlane((g * GM + r % gm) * G256_BM);
-        n0 = __builtin_amdgcn_readfirstlane((r / gm) * BN);
-        split = __builtin_amdgcn_readfirstlane(split);
-    };
+// LNF (LayerNorm folded into the GEMMs around it, kernels.h: launch_gemm256w_ln; 0 in every kernel of the default path):
+//   1  EPI_RESID producer: next to the fp32 result a bf16 copy of it (ln_x) and, per row and wave column range, the partial
+//      (sum, sum of squares) of the stored values (ln_part);
+//   2  EPI_BF16 / EPI_GELU consumer: acc <- a[row] * acc + b[row] * c1[col] before the usual epilogue (bias = c2).
+#define W_KERNEL_TEMPLATE template <int EPI, bool PLAIN, int NJ>
+#define W_KERNEL_NAME gemm256w_bf16_kernel
+#define W_KERNEL_LNF 0
+#include "gemm256w_kernel.h"
+#undef W_KERNEL_TEMPLATE
+#undef W_KERNEL_NAME
+#undef W_KERNEL_LNF
+#define W_KERNEL_TEMPLATE template <int EPI, bool PLAIN, int NJ, int LNF_>
+#define W_KERNEL_NAME gemm256w_ln_kernel
+#define W_KERNEL_LNF LNF_
+#include "gemm256w_kernel.h"
+#undef W_KERNEL_TEMPLATE
+#undef W_KERNEL_NAME
+#undef W_KERNEL_LNF
 
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
-
-    // ---- LDS-DMA addressing: wave w fills rows [64 w, 64 w + 64) of the A tile and [8 NJ w, 8 NJ (w + 1)) of
-    //      the W tile, 8 rows per instruction; lane l -> row l / 8, 16-byte chunk (l % 8) ^ (row % 8) of the
-    //      128-byte k-slice.  One descriptor per MATRIX (both below 2 GiB, checked by the launcher); a tile's
-    //      byte offset and the K offset go into the per-lane offset, the row group into the scalar offset.
-    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7FFFFFFF, 0x00020000);
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
-    const unsigned lchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
-    const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
-    const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
-    const unsigned rgA = (unsigned)p.lda * 16u, rgW = (unsigned)p.ldw * 16u;      // bytes per 8-row group
-    const unsigned sA0 = (unsigned)wave * 8u * rgA, sW0 = (unsigned)wave * (unsigned)NJ * rgW;
-    char* const dmaA = smem + wave * 8192;
-    char* const dmaW = smem + G256_TILE_BYTES + wave * (NJ * 1024);
-    auto tile_off_a = [&](int m0, int split) { return ((unsigned)m0 * (unsigned)p.lda + (unsigned)split * (unsigned)Ks) * 2u; };
-    auto tile_off_w = [&](int n0, int split) { return ((unsigned)n0 * (unsigned)p.ldw + (unsigned)split * (unsigned)Ks) * 2u; };
-
-    // one of the NR loads of a K-step: d < 8 -> A row group d, else W row group d - 8
-    auto dma = [&](int stage, int d, unsigned vA, unsigned vW) {
-        if (d < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, VR_LDS(dmaA + stage * W_STAGE + d * 1024), 16, vA, sA0 + d * rgA, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, VR_LDS(dmaW + stage * W_STAGE + (d - 8) * 1024), 16, vW, sW0 + (d - 8) * rgW, 0, 0);
-    };
-
-    // ---- fragment addressing: row = strip * 16 + fr, chunk (kk * 4 + fq) ^ (row & 7).  One LDS pointer per
-    //      (operand, stage, k-half) held in a VGPR; the strip is an immediate offset (strip * 2 KiB).
-    typedef const __attribute__((address_space(3))) bf16x8* frag_p;
-    frag_p pA[2][2], pW[2][2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ch = ((kk * 4 + fq) ^ (fr & 7)) << 4;
-            pA[st][kk] = (frag_p)VR_LDS(smem + st * W_STAGE + (wm * 128 + fr) * 128 + ch);
-            pW[st][kk] = (frag_p)VR_LDS(smem + st * W_STAGE + G256_TILE_BYTES + (wn * 16 * NJ + fr) * 128 + ch);
-            asm volatile("" : "+v"(pA[st][kk]), "+v"(pW[st][kk]));
-        }
-
-    bf16x8 a0[8], w0[NJ], a1[8], w1[NJ];
-    int m0, n0, split;
-    coords(my_first, m0, n0, split);
-    unsigned curA = tile_off_a(m0, split), curW = tile_off_w(n0, split);
-#if defined(VR_W_RESID_TOUCH) && VR_W_RESID_TOUCH
-    // A/B knob: the fp32 residual tile this workgroup will read-modify-write is asked for NOW (one dword per 128-B line,
-    // LDS-DMA'd into the wave's staging area: no register, oldest loads of the wave, so every later vmcnt wait covers them)
-    if constexpr (EPI == EPI_RESID) {
-        if (!p.rowmap) {
-            char* const dump = smem + 2 * W_STAGE + wave * W_STAGING;
-            constexpr int LPR = BN * 4 / 128;                       // 128-B lines per tile row
-#pragma unroll
-            for (int i = 0; i < (64 * LPR + 63) / 64; ++i) {
-                const int li = i * 64 + lane, row = min(m0 + wave * 64 + li / LPR, p.M - 1), seg = li % LPR;
-                const float* a = p.resid + (size_t)row * p.ldo + min(n0 + seg * 32, p.N - 4);
-                __builtin_amdgcn_global_load_lds(VR_GLOBAL(a), VR_LDS(dump), 4, 0, 0);
-            }
-        }
-    }
-#endif
-
-    // ---- prologue: K-steps 0 and 1 in flight, the accumulators zeroed under their latency (256 register writes:
-    //      half a microsecond), k-half-0 fragments of step 0 requested
-    {
-        const unsigned k1 = nk > 1 ? (unsigned)(GEMM_BK * 2) : W_OOB;
-#pragma unroll
-        for (int d = 0; d < NR; ++d) dma(0, d, lofA + curA, lofW + curW);
-#pragma unroll
-        for (int d = 0; d < NR; ++d) dma(1, d, lofA + curA + k1, lofW + curW + k1);
-        W_FOR_EACH_ACC(W_ZERO)
-        if constexpr (NJ == 8) VR_WAIT_VM_BARRIER(16); else VR_WAIT_VM_BARRIER(14);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) w0[j] = pW[0][0][j * 128];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a0[i] = pA[0][0][i * 128];
-    }
-#ifdef VR_W_TIMING
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    tm1 = __builtin_amdgcn_s_memrealtime();
-    cy1 = __builtin_amdgcn_s_memtime();
-#endif
-
-    {
-        // the loads of the two K-steps past the end of K go nowhere (out of the descriptors' range)
-        const unsigned nxtA = W_OOB, nxtW = W_OOB;
-
-        auto step = [&](auto stage_c, int kt) {
-            constexpr int S = decltype(stage_c)::value;
-            const int k2 = kt + 2;
-            const unsigned vA = lofA + (k2 < nk ? curA + (unsigned)k2 * (GEMM_BK * 2) : nxtA + (unsigned)(k2 - nk) * (GEMM_BK * 2));
-            const unsigned vW = lofW + (k2 < nk ? curW + (unsigned)k2 * (GEMM_BK * 2) : nxtW + (unsigned)(k2 - nk) * (GEMM_BK * 2));
-            __builtin_amdgcn_sched_barrier(0);
-            // one auxiliary operation may follow each MFMA; sl = its slot in the phase
-            auto aux1 = [&](int sl) {
-                if (sl < 2 * NR && (sl & 1) == 0) {
-                    const int q = sl >> 1;
-                    if (q < NJ) w1[q] = pW[S][1][q * 128];
-                    else a1[q - NJ] = pA[S][1][(q - NJ) * 128];
-                }
-                if (sl == SB1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (sl >= SB1 + 2 && (sl - (SB1 + 2)) % DS == 0) dma(S, (sl - (SB1 + 2)) / DS, vA, vW);     // loads 0 .. D1-1
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            auto aux2 = [&](int sl) {
-                if (sl == SB2) { if constexpr (D1 == 5) VR_WAIT_VM_BARRIER(5); else VR_WAIT_VM_BARRIER(4); }
-                if (sl >= SB2 + 3 && (sl - (SB2 + 3)) % DS == 0 && D1 + (sl - (SB2 + 3)) / DS < NR)
-                    dma(S, D1 + (sl - (SB2 + 3)) / DS, vA, vW);                                              // loads D1 .. NR-1
-                if (sl >= SB2 + 2 && sl < SB2 + 2 + 2 * NR && ((sl - SB2) & 1) == 0) {
-                    const int q = (sl - (SB2 + 2)) >> 1;
-                    if (q < NJ) w0[q] = pW[S ^ 1][0][q * 128];
-                    else a0[q - NJ] = pA[S ^ 1][0][(q - NJ) * 128];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            // ---- phase 1: k-half 0, phase 2: k-half 1 (accumulator n: strip n / 8, fragment n % 8 < NJ)
-#define W_P1(n, R, C0, C1, C2, C3) \
-            if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w0[(n) & 7], a0[(n) >> 3]); aux1(((n) >> 3) * NJ + ((n) & 7)); }
-#define W_P2(n, R, C0, C1, C2, C3) \
-            if (((n) & 7) < NJ) { W_MFMA(R, C0, C1, C2, C3, w1[(n) & 7], a1[(n) >> 3]); aux2(((n) >> 3) * NJ + ((n) & 7)); }
-            W_FOR_EACH_ACC(W_P1)
-            W_FOR_EACH_ACC(W_P2)
-#undef W_P1
-#undef W_P2
-        };
-
-        for (int kt = 0; kt < nk; kt += 2) {
-            step(std::integral_constant<int, 0>{}, kt);
-            if (kt + 1 >= nk) break;
-            step(std::integral_constant<int, 1>{}, kt + 1);
-        }
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU reads (see the W_MFMA note)
-#ifdef VR_W_TIMING
-        tm2 = __builtin_amdgcn_s_memrealtime();
-        cy2 = __builtin_amdgcn_s_memtime();
-#endif
-
-        // ---- epilogue of tile (m0, n0, split).  The stages may already be receiving the next tile: staging goes
-        //      through this wave's 4 KiB above them, one piece at a time (a wave's LDS operations execute in order).
-        //      Pieces of 32 accumulator registers are read back into VGPRs one after the other; the scheduling
-        //      barriers keep hipcc from pulling later read-backs up and running out of VGPRs.
-        const int mrow0 = m0 + wm * 128, nb0 = n0 + wn * (16 * NJ);
-        char* const wl0 = smem + 2 * W_STAGE + wave * W_STAGING;
-        bool plain_resid = false;
-        if constexpr (EPI == EPI_RESID) plain_resid = !p.rowmap;
-        if constexpr (EPI == EPI_RESID) {
-            // out = resid + alpha * (acc + bias), fp32, in place, piece by piece (below).  Addresses are clamped for
-            // rows >= M / columns >= N, the stores predicated.
-            if (plain_resid) {
-                constexpr int MI = 2;           // pieces of 32 rows x 16 NF columns: 8 per wave
-                const float* __restrict__ resid = p.resid;
-                float* __restrict__ out = (float*)p.out;
-                // The residual of piece q + RD is requested before piece q is combined and stored (one wave per SIMD, nothing else
-                // hides the latency).  RD = 1 is enough: round 4 measured RD = 1 .. 6 in-model on one box (the ring lives in the
-                // K-loop's dead fragment registers) — proj 3.31-3.36 ms, fc2 7.89-8.00 ms per step for every depth — while the
-                // same epilogue WITHOUT its reads runs proj at 2.35 / fc2 at 7.02 and WITHOUT its stores at 2.50 / 6.94, and an
-                // early touch of the residual lines into the L2 is slower (3.53 / 8.42).  So the read-modify-write is paced by
-                // the HBM moving 302 MB per launch in the epilogue phases of the rounds (all CUs leave their K-loops together:
-                // ~3.8 TB/s of mixed reads and writes there, nothing during the K-loops), not by the depth of this wave's
-                // prefetch; overlapping it needs the NEXT tile's K-loop on the same CU, i.e. a second accumulator set.
-#ifndef VR_W_RESID_DEPTH
-#define VR_W_RESID_DEPTH 1
-#endif
-                // (the 256-column tile keeps 256 accumulators: a ring deeper than 3 of its 32-register pieces does not fit beside them)
-                constexpr int RD = NJ == 6 ? VR_W_RESID_DEPTH : (VR_W_RESID_DEPTH < 3 ? VR_W_RESID_DEPTH : 3);
-                f32x4 rs[RD + 1][MI][NF];
-                auto load_piece = [&](int q, f32x4 (&dst)[MI][NF]) {
-                    const int h = q & 1, sg = q >> 1;
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const size_t ro = (size_t)min(mrow0 + (sg * MI + i) * 16 + fr, p.M - 1) * p.ldo;
-#pragma unroll
-                        for (int j = 0; j < NF; ++j) {
-#if defined(VR_W_RESID_DIAG) && VR_W_RESID_DIAG == 1      // diagnostic build: no residual reads (WRONG results; what would hiding them buy?)
-                            dst[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; (void)ro;
-#else
-                            dst[i][j] = *reinterpret_cast<const f32x4*>(resid + ro + min(nb0 + (h * NF + j) * 16 + fq * 4, p.N - 4));
-#endif
-                        }
-                    }
-                };
-#pragma unroll
-                for (int q = 0; q < RD; ++q) load_piece(q, rs[q]);
-                f32x4 bias[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(nb0 + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int h = q & 1, sg = q >> 1;
-                    if (q + RD < 8) load_piece(q + RD, rs[(q + RD) % (RD + 1)]);
-                    f32x4 acc[MI][NF];
-#define W_RD(n, R, C0, C1, C2, C3) \
-                    if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
-                    W_FOR_EACH_ACC(W_RD)
-#undef W_RD
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const int m = mrow0 + (sg * MI + i) * 16 + fr;
-#pragma unroll
-                        for (int j = 0; j < NF; ++j) {
-                            const int n = nb0 + (h * NF + j) * 16 + fq * 4;
-#if defined(VR_W_RESID_DIAG) && VR_W_RESID_DIAG == 2      // diagnostic build: no stores (WRONG results)
-                            const f32x4 vv = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
-                            if (m < p.M && n < p.N && vv[0] == 123456.78f)
-                                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = vv;
-#else
-                            if (m < p.M && n < p.N)
-                                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
-#endif
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        if (!plain_resid) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                constexpr int MI = 2;
-                const int h = q & 1, sg = q >> 1;       // column half, 32-row strip group
-                f32x4 acc[MI][NF];                      // [16-row strip][16-column fragment]
-#define W_RD(n, R, C0, C1, C2, C3) \
-                if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
-                W_FOR_EACH_ACC(W_RD)
-#undef W_RD
-                const int mr = mrow0 + sg * 32, nb = nb0 + h * (16 * NF);
-                bool done = false;
-                if constexpr (EPI == EPI_F32) {
-                    // fp32 outputs without per-row lookups (incl. the split-K partial products: split s writes to its
-                    // own plane, the bias goes with split 0): bias requested once per piece, predicated vector stores.
-                    // The shared per-row epilogue (a branch nest and a dependent bias load per fragment) took 16.9 us
-                    // of a 34 us launch on the decoder's o-projection shape.
-                    if (!p.rowmap && !p.rowbias) {
-                        float* __restrict__ out = (float*)p.out + (size_t)split * p.split_stride;
-                        const float* bp = split == 0 ? p.bias : nullptr;
-                        f32x4 bias[NF];
-#pragma unroll
-                        for (int j = 0; j < NF; ++j)
-                            bias[j] = bp ? *reinterpret_cast<const f32x4*>(bp + min(nb + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) {
-                            const int m = mr + i * 16 + fr;
-#pragma unroll
-                            for (int j = 0; j < NF; ++j) {
-                                const int n = nb + j * 16 + fq * 4;
-                                if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = acc[i][j] + bias[j];
-                            }
-                        }
-                        done = true;
-                    } else if (ks > 1) {
-                        GemmArgs ps = p;
-                        ps.out = (float*)p.out + (size_t)split * p.split_stride;
-                        if (split > 0) ps.bias = nullptr;
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI_F32, NF>(acc[i], ps, mr + i * 16 + fr, nb, fq);
-                        done = true;
-                    }
-                }
-                if constexpr (EPI == EPI_RESID) {       // (row-mapped residual outputs)
-                    gemm_epilogue_resid_tile<MI, NF, 2>(acc, p, mr + fr, nb, fq);
-                    done = true;
-                }
-                if constexpr (NF == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE)) {
-                    if constexpr (PLAIN) {
-                        gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mr, nb, lane, wl0);
-                        done = true;
-                    } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
-                        gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl0);
-                        done = true;
-                    }
-                }
-                if constexpr (!PLAIN) {
-                    if (!done) {
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) gemm_epilogue_row<EPI, NF>(acc[i], p, mr + i * 16 + fr, nb, fq);
-                    }
-                }
-                // (lookup-free pieces may overlap in pairs; they share the staging buffer, whose accesses hipcc keeps
-                // in program order)
-                if (!PLAIN || (q & 1)) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-#ifdef VR_W_TIMING
-    if (threadIdx.x == 0 && p.rope_table) {
-        const unsigned long long tm3 = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tm4 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* d = (unsigned long long*)p.rope_table + (size_t)blockIdx.x * 16;
-        d[0] = tm0; d[1] = tm1; d[2] = tm2; d[3] = tm3; d[4] = tm4;
-        d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
-        d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
-        d[7] = cy2 - cy1;                                         // shader clocks spent in the K-loop
-    }
-#endif
+template <int EPI, bool PLAIN, int NJ, int LNF>
+static hipError_t launch_wp_ln(GemmArgs a, hipStream_t s) {
+    constexpr int BN = 32 * NJ;
+    const int tn = (a.N + BN - 1) / BN, tm = (a.M + G256_BM - 1) / G256_BM;
+    if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
+    if (!gemm256w_fits(a, BN) || a.ksplit > 1) return hipErrorInvalidValue;
+    auto k = gemm256w_ln_kernel<EPI, PLAIN, NJ, LNF>;
+    constexpr int smem = LNF == 2 ? W_SMEM_BYTES_LN : W_SMEM_BYTES;
+    static unsigned long long attr = 0;     // bit d: set on device d
+    set_max_dynamic_lds((const void*)k, smem, attr);
+    hipLaunchKernelGGL(k, dim3(tn * tm), dim3(256), smem, s, a);
+    return hipGetLastError();
 }
 
 template <int EPI, bool PLAIN, int NJ>
@@ -441,6 +143,21 @@ hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_ROPE: return launch_w<EPI_ROPE>(a, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+// LayerNorm folded into the GEMMs around it (kernels.h)
+hipError_t launch_gemm256w_ln(const GemmArgs& a, int epi, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.rowmap || a.rowbias) return hipErrorInvalidValue;
+    if (epi == EPI_RESID) {
+        if (!a.ln_x || !a.ln_part || a.N % 192 || a.ln_parts != (a.N / 192) * 2 || !a.resid || (a.ln_ldx & 3)) return hipErrorInvalidValue;
+        return launch_wp_ln<EPI_RESID, false, 6, 1>(a, s);
+    }
+    if (epi == EPI_BF16 || epi == EPI_GELU) {
+        if (!a.ln_ab || !a.ln_c1 || (a.N & 7) || (a.ldo & 7)) return hipErrorInvalidValue;
+        return epi == EPI_BF16 ? launch_wp_ln<EPI_BF16, true, 8, 2>(a, s) : launch_wp_ln<EPI_GELU, true, 8, 2>(a, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 // 256 x 192 tile: N % 192 == 0, residual (the SigLIP proj / fc2 GEMMs) and fp32 (split-K partial products of the
