@@ -52,7 +52,7 @@ struct vr_model_s {
     bool finalized = false, taps_on = false;
     int pool_mode = 0;                        // VR_POOL_*
     bool borrowed = false;                    // vr_model_clone: weights belong to another handle
-    bool ln_fold = false;                     // VR_VIT_LN_FOLD=1 at vr_model_create: the ViT blocks' LayerNorms folded into the GEMMs around them
+    int ln_fold = 0;                          // VR_VIT_LN_FOLD=1 / 2 at vr_model_create: the ViT blocks' LayerNorms folded into the GEMMs around them
     // dims
     int D = 0, Dp = 0, F = 0, Fp = 0, E = 0, I = 0, Ip = 0, Kpe = 0, Kpe_p = 0, Q = 0;
     // weights
@@ -169,8 +169,8 @@ extern "C" int vr_model_create(int device_id, const vr_config_t* cfg, vr_model_t
     m->layers.resize(c.num_layers);
     // experimental (built in round 4 without a GPU at hand, to be measured): the ViT blocks' LayerNorms folded into the
     // GEMMs around them.  Needs the 256 x 192 residual tile (vit_dim % 192 == 0, no padding columns).
-    const char* lf = getenv("VR_VIT_LN_FOLD");
-    m->ln_fold = lf && lf[0] && lf[0] != '0' && c.vit_dim % 192 == 0 && m->Dp == c.vit_dim;
+    const char* lf = getenv("VR_VIT_LN_FOLD");          // 1: a statistics launch between producer and consumer; 2: the consumer computes them itself
+    m->ln_fold = (lf && lf[0] >= '1' && lf[0] <= '2' && c.vit_dim % 192 == 0 && m->Dp == c.vit_dim && c.vit_dim / 192 <= 8) ? lf[0] - '0' : 0;
     *out = m;
     return VR_OK;
 }
@@ -473,7 +473,7 @@ static int alloc_workspace(vr_model_s* m) {
     VRCHK(m->w_imgptr.alloc((size_t)c.max_images * 8));
     VRCHK(m->w_out.alloc((size_t)c.max_seqs * E * 4));
     if (m->ln_fold) {
-        VRCHK(m->w_lnpart.alloc((size_t)M * (2 * (m->D / 192)) * 2 * 4));
+        VRCHK(m->w_lnpart.alloc((size_t)M * (2 * (m->D / 192)) * 2 * 4 + 256));      // (+ a row's worth of slack behind the last row)
         VRCHK(m->w_lnab.alloc((size_t)M * 2 * 4));
     }
     if (c.text_split_precision) {
@@ -732,15 +732,20 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     const int ldqkv = pad128(3 * D);
     // ln_fold: the residual GEMMs (proj, fc2) leave the bf16 rows of the stream in w_xn and per-row partial sums; the GEMM behind
     // a LayerNorm runs on those rows with pre-scaled weights and applies (rstd, -mean rstd) per row in its epilogue
-    const bool fold = m->ln_fold && (size_t)pad256l(M) * (size_t)std::max(m->Fp, ldqkv) * 2 < (1ull << 31);   // (gemm256w_fits: 32-bit LDS-DMA offsets)
+    const bool fold = m->ln_fold != 0 && (size_t)pad256l(M) * (size_t)std::max(m->Fp, ldqkv) * 2 < (1ull << 31);   // (gemm256w_fits: 32-bit LDS-DMA offsets)
     const int ln_parts = 2 * (D / 192);
     auto fold_emit = [&](GemmArgs& a) { a.ln_x = m->w_xn.p; a.ln_ldx = Dp; a.ln_part = m->w_lnpart.as<float>(); a.ln_parts = ln_parts; };
-    auto fold_use = [&](GemmArgs& a, const Vec& c1) { a.ln_ab = m->w_lnab.as<float>(); a.ln_c1 = c1.v.as<float>(); };
+    const bool fold_stats = m->ln_fold == 1;      // a statistics launch; else the consuming GEMM's workgroups compute their rows' themselves
+    auto fold_use = [&](GemmArgs& a, const Vec& c1) {
+        a.ln_c1 = c1.v.as<float>();
+        if (fold_stats) a.ln_ab = m->w_lnab.as<float>();
+        else { a.ln_part = m->w_lnpart.as<float>(); a.ln_parts = ln_parts; a.ln_dim = D; a.ln_eps = c.vit_ln_eps; }
+    };
     for (int l = 0; l < c.vit_depth; ++l) {
         const VitBlock& b = m->blocks[l];
         const bool fold_qkv = fold && l > 0;
         if (!fold_qkv) HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
-        else HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
+        else if (fold_stats) HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
         VRCHK(prof_begin(m, VR_PROF_VIT_QKV, s));
         if (fold_qkv) {
             GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv_f, M, m->w_qkv.p, ldqkv);
@@ -767,7 +772,7 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         }
         VRCHK(prof_end(m, VR_PROF_VIT_PROJ, 2.0 * M * D * D, s));
         if (!fold) HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
-        else HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
+        else if (fold_stats) HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC1, s));
         if (fold) {
             GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1_f, M, m->w_mlp.p, m->Fp);
@@ -1618,13 +1623,14 @@ extern "C" int vr_synth_pages(int device_id, uint8_t* out, int32_t n, int32_t si
 // ------------------------------------------------ LayerNorm folded into GEMMs: op level ---
 extern "C" int vr_op_gemm_ln(int device_id, const void* A, int32_t lda, const void* W, int32_t ldw, int32_t M, int32_t N, int32_t K,
                              int32_t epilogue, const float* bias, const float* resid, void* out, int32_t ldo, void* ln_x,
-                             int32_t ln_ldx, float* ln_part, int32_t ln_parts, const float* ln_ab, const float* ln_c1, void* stream) {
+                             int32_t ln_ldx, float* ln_part, int32_t ln_parts, const float* ln_ab, const float* ln_c1, int32_t ln_dim,
+                             float ln_eps, void* stream) {
     if (!A || !W || !out) return fail(VR_ERR_INVALID, "NULL argument");
     if (M <= 0 || K % 64 || N % 128) return fail(VR_ERR_INVALID, "need M > 0, N %% 128 == 0, K %% 64 == 0");
     VRCHK(set_dev(device_id));
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid; a.alpha = 1.0f;
-    a.out = out; a.ldo = ldo; a.ln_x = ln_x; a.ln_ldx = ln_ldx; a.ln_part = ln_part; a.ln_parts = ln_parts; a.ln_ab = ln_ab; a.ln_c1 = ln_c1;
+    a.out = out; a.ldo = ldo; a.ln_x = ln_x; a.ln_ldx = ln_ldx; a.ln_part = ln_part; a.ln_parts = ln_parts; a.ln_ab = ln_ab; a.ln_c1 = ln_c1; a.ln_dim = ln_dim; a.ln_eps = ln_eps;
     HIPCHK(launch_gemm256w_ln(a, epilogue, (hipStream_t)stream));
     return VR_OK;
 }

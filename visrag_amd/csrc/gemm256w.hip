@@ -71,7 +71,8 @@ constexpr int W_SMEM_BYTES_LN = W_SMEM_BYTES + 4 * W_LN_AB;
 // LNF (LayerNorm folded into the GEMMs around it, kernels.h: launch_gemm256w_ln; 0 in every kernel of the default path):
 //   1  EPI_RESID producer: next to the fp32 result a bf16 copy of it (ln_x) and, per row and wave column range, the partial
 //      (sum, sum of squares) of the stored values (ln_part);
-//   2  EPI_BF16 / EPI_GELU consumer: acc <- a[row] * acc + b[row] * c1[col] before the usual epilogue (bias = c2).
+//   2  EPI_BF16 / EPI_GELU consumer: acc <- a[row] * acc + b[row] * c1[col] before the usual epilogue (bias = c2);
+//   3  the same, (a, b) = (rstd, -mean rstd) computed here from the producer's partial sums (fp32), no statistics launch.
 #define W_KERNEL_TEMPLATE template <int EPI, bool PLAIN, int NJ>
 #define W_KERNEL_NAME gemm256w_bf16_kernel
 #define W_KERNEL_LNF 0
@@ -94,7 +95,7 @@ static hipError_t launch_wp_ln(GemmArgs a, hipStream_t s) {
     if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
     if (!gemm256w_fits(a, BN) || a.ksplit > 1) return hipErrorInvalidValue;
     auto k = gemm256w_ln_kernel<EPI, PLAIN, NJ, LNF>;
-    constexpr int smem = LNF == 2 ? W_SMEM_BYTES_LN : W_SMEM_BYTES;
+    constexpr int smem = LNF >= 2 ? W_SMEM_BYTES_LN : W_SMEM_BYTES;
     static unsigned long long attr = 0;     // bit d: set on device d
     set_max_dynamic_lds((const void*)k, smem, attr);
     hipLaunchKernelGGL(k, dim3(tn * tm), dim3(256), smem, s, a);
@@ -154,8 +155,10 @@ hipError_t launch_gemm256w_ln(const GemmArgs& a, int epi, hipStream_t s) {
         return launch_wp_ln<EPI_RESID, false, 6, 1>(a, s);
     }
     if (epi == EPI_BF16 || epi == EPI_GELU) {
-        if (!a.ln_ab || !a.ln_c1 || (a.N & 7) || (a.ldo & 7)) return hipErrorInvalidValue;
-        return epi == EPI_BF16 ? launch_wp_ln<EPI_BF16, true, 8, 2>(a, s) : launch_wp_ln<EPI_GELU, true, 8, 2>(a, s);
+        if (!a.ln_c1 || (a.N & 7) || (a.ldo & 7)) return hipErrorInvalidValue;
+        if (a.ln_ab) return epi == EPI_BF16 ? launch_wp_ln<EPI_BF16, true, 8, 2>(a, s) : launch_wp_ln<EPI_GELU, true, 8, 2>(a, s);
+        if (!a.ln_part || a.ln_parts <= 0 || a.ln_parts > 16 || a.ln_dim <= 0) return hipErrorInvalidValue;
+        return epi == EPI_BF16 ? launch_wp_ln<EPI_BF16, true, 8, 3>(a, s) : launch_wp_ln<EPI_GELU, true, 8, 3>(a, s);
     }
     return hipErrorInvalidValue;
 }

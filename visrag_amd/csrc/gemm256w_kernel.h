@@ -5,7 +5,7 @@ W_KERNEL_TEMPLATE
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void W_KERNEL_NAME(GemmArgs p) {
     constexpr int LNF = W_KERNEL_LNF;
     static_assert(NJ == 8 || (NJ == 6 && !PLAIN), "wave tile 128 x 128 or 128 x 96");
-    static_assert(LNF == 0 || (LNF == 1 && EPI == EPI_RESID) || (LNF == 2 && PLAIN && (EPI == EPI_BF16 || EPI == EPI_GELU)), "LNF forms");
+    static_assert(LNF == 0 || (LNF == 1 && EPI == EPI_RESID) || ((LNF == 2 || LNF == 3) && PLAIN && (EPI == EPI_BF16 || EPI == EPI_GELU)), "LNF forms");
     constexpr int BN = 32 * NJ;                 // tile columns
     constexpr int NS = 8 * NJ;                  // MFMAs per phase (slots)
     constexpr int NR = 8 + NJ;                  // fragment reads per k-half = LDS-DMA loads per K-step and wave
@@ -113,6 +113,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
 
+    // LNF = 3: thread t asks for the partial sums of row m0 + t now (its oldest loads) and turns them into (a, b) under the
+    // latency of the prologue's operand loads; the prologue's barrier publishes the 256 pairs to the four waves
+    constexpr int LN_MAXP = 16;
+    [[maybe_unused]] f32x2 ln_pv[LNF == 3 ? LN_MAXP : 1];
+    if constexpr (LNF == 3) {
+        const f32x2* pp = reinterpret_cast<const f32x2*>(p.ln_part) + (size_t)min(m0 + (int)threadIdx.x, p.M - 1) * p.ln_parts;
+#pragma unroll
+        for (int i = 0; i < LN_MAXP; ++i) ln_pv[i] = i < p.ln_parts ? pp[i] : f32x2{0.f, 0.f};
+    }
+
     // ---- prologue: K-steps 0 and 1 in flight, the accumulators zeroed under their latency (256 register writes:
     //      half a microsecond), k-half-0 fragments of step 0 requested
     {
@@ -122,6 +132,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int d = 0; d < NR; ++d) dma(1, d, lofA + curA + k1, lofW + curW + k1);
         W_FOR_EACH_ACC(W_ZERO)
+        if constexpr (LNF == 3) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXP; ++i) { s1 += ln_pv[i][0]; s2 += ln_pv[i][1]; }       // (index order: fixed)
+            const float inv = 1.0f / (float)p.ln_dim;
+            const float mean = s1 * inv;
+            const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f);
+            const float rstd = 1.0f / __builtin_sqrtf(var + p.ln_eps);
+            typedef __attribute__((address_space(3))) f32x2* ab_w;
+            ((ab_w)VR_LDS(smem + W_SMEM_BYTES))[threadIdx.x] = f32x2{rstd, -mean * rstd};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               // (written before the barrier below)
+        }
         if constexpr (NJ == 8) VR_WAIT_VM_BARRIER(16); else VR_WAIT_VM_BARRIER(14);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) w0[j] = pW[0][0][j * 128];
@@ -345,10 +367,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     gemm_epilogue_resid_tile<MI, NF, 2>(acc, p, mr + fr, nb, fq);
                     done = true;
                 }
-                if constexpr (LNF == 2) {
+                if constexpr (LNF == 2 || LNF == 3) {
                     // acc <- a[row] acc + b[row] c1[col]   (then bias = c2 and the activation, below)
                     typedef const __attribute__((address_space(3))) f32x2* ab_p;
-                    const ab_p abl = (ab_p)VR_LDS(smem + W_SMEM_BYTES + wave * W_LN_AB);
+                    const ab_p abl = (ab_p)VR_LDS(smem + W_SMEM_BYTES + (LNF == 2 ? wave * W_LN_AB : wm * 128 * 8));
                     f32x4 c1v[NF];
 #pragma unroll
                     for (int j = 0; j < NF; ++j) c1v[j] = *reinterpret_cast<const f32x4*>(p.ln_c1 + min(nb + j * 16 + fq * 4, p.N - 4));

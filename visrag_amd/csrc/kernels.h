@@ -37,6 +37,7 @@ struct GemmArgs {
     float* ln_part; int ln_parts;    //   ... and per (row, 96-column half tile) the partial (sum, sum of squares): f32 [M][ln_parts][2]
     const float* ln_ab;              // EPI_BF16 / EPI_GELU consumer: per row (a, b) = (rstd, -mean * rstd): f32 [M][2]
     const float* ln_c1;              //   per column c1[n] = sum_k W'[n][k]:  out = epi(a * acc + b * c1 + bias)   (bias = c2)
+    int ln_dim; float ln_eps;        //   ln_ab == null: (a, b) computed by the consumer itself from ln_part / ln_parts (<= 16) over ln_dim columns
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // 256x192 tile (gemm192.hip): N % 192 == 0, epilogues BF16 / GELU / F32 / RESID only
@@ -52,7 +53,8 @@ hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
 // its epilogue, and the residual GEMM that PRODUCES x writes those bf16 rows and per-row partial sums next to its fp32
 // result: the LayerNorm kernel between them (226 MB per launch of the ViT: 44 us, 52 per step) is gone.
 //   EPI_RESID (256x192 tile, N % 192 == 0): also writes ln_x and ln_part;
-//   EPI_BF16 / EPI_GELU (256x256 tile, plain outputs): applies ln_ab / ln_c1.
+//   EPI_BF16 / EPI_GELU (256x256 tile, plain outputs): applies ln_ab / ln_c1 — or, with ln_ab == null, computes a tile's 256
+//   (a, b) itself from the partial sums while its first operand loads are in flight (no statistics launch in between).
 hipError_t launch_gemm256w_ln(const GemmArgs& a, int epilogue, hipStream_t s);
 // partial sums -> (rstd, -mean rstd) per row (biased variance over `dim` columns, like nn.LayerNorm)
 hipError_t launch_ln_fold_stats(const float* part, int parts, int rows, int dim, float eps, float* ab, hipStream_t s);
