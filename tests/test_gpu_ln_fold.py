@@ -2,9 +2,9 @@
 them (include/visrag_hip.h: vr_op_gemm_ln; VR_VIT_LN_FOLD=1 at vr_model_create).  Written in round 4 without a GPU at
 hand — the default path does not run any of this, and these tests are skipped until the code has been run once:
 
-  * vr_op_ln_fold_weights against torch (W' = bf16(gamma o W), c1, c2);
-  * the residual GEMM with the extra outputs: fp32 result BIT-IDENTICAL to the default residual kernel, bf16 copy ==
-    bf16(result), partial sums == torch's over the same column ranges;
+  * vr_op_ln_fold_weights against torch (c1 = W gamma, c2 = bias + W beta);
+  * the residual GEMM with the extra outputs: fp32 result BIT-IDENTICAL to the default residual kernel, bf16 rows ==
+    bf16(result o gamma), partial sums == torch's over the same column ranges;
   * vr_op_ln_fold_stats against torch;
   * the consuming GEMMs (plain and GELU) against LayerNorm -> default GEMM on the same rows;
   * the encoder with the knob against the encoder without, full dims (torch fp32 reference of the op: nn.LayerNorm)."""
@@ -28,12 +28,11 @@ D = 1152
 def _fold_weights(W, gamma, beta, bias):
     lib = _lib.load()
     n_pad, ldw = W.shape
-    W2 = torch.empty_like(W)
     c1 = torch.empty(n_pad, device="cuda")
     c2 = torch.empty(n_pad, device="cuda")
-    _lib.check(lib.vr_op_ln_fold_weights(0, P(W), n_pad, gamma.numel(), ldw, P(gamma), P(beta), P(bias), P(W2), P(c1), P(c2), None))
+    _lib.check(lib.vr_op_ln_fold_weights(0, P(W), n_pad, gamma.numel(), ldw, P(gamma), P(beta), P(bias), P(c1), P(c2), None))
     torch.cuda.synchronize()
-    return W2, c1, c2
+    return c1, c2
 
 
 def test_fold_weights_match_torch():
@@ -45,14 +44,12 @@ def test_fold_weights_match_torch():
     gamma = 1 + 0.3 * torch.randn(k, generator=g, device="cuda")
     beta = 0.2 * torch.randn(k, generator=g, device="cuda")
     bias = torch.randn(n_pad, generator=g, device="cuda")
-    W2, c1, c2 = _fold_weights(W, gamma, beta, bias)
-    ref = (W[:, :k].float() * gamma).to(torch.bfloat16)
-    assert torch.equal(W2[:, :k], ref) and torch.equal(W2[:, k:], W[:, k:])
-    torch.testing.assert_close(c1, ref.double().sum(1).float(), atol=1e-5, rtol=1e-5)
+    c1, c2 = _fold_weights(W, gamma, beta, bias)
+    torch.testing.assert_close(c1, (W[:, :k].double() * gamma.double()).sum(1).float(), atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(c2, (bias.double() + (W[:, :k].double() * beta.double()).sum(1)).float(), atol=1e-5, rtol=1e-5)
 
 
-def _producer(A, W, bias, resid):
+def _producer(A, W, bias, resid, gamma):
     lib = _lib.load()
     M, K = A.shape
     N = W.shape[0]
@@ -60,7 +57,7 @@ def _producer(A, W, bias, resid):
     xb = torch.zeros((Ap.shape[0], N), dtype=torch.bfloat16, device="cuda")
     parts = 2 * N // 192
     part = torch.zeros((Ap.shape[0], parts, 2), device="cuda")
-    _lib.check(lib.vr_op_gemm_ln(0, P(Ap), K, P(W), K, M, N, K, 3, P(bias), P(out), P(out), N, P(xb), N, P(part), parts, None, None, 0, 0.0, None))
+    _lib.check(lib.vr_op_gemm_ln(0, P(Ap), K, P(W), K, M, N, K, 3, P(bias), P(out), P(out), N, P(xb), N, P(gamma), P(part), parts, None, None, 0, 0.0, None))
     torch.cuda.synchronize()
     return out[:M], xb[:M], part[:M]
 
@@ -72,10 +69,11 @@ def test_residual_gemm_with_bf16_copy_and_partial_sums(M, K):
     W = (torch.randn((D, K), generator=g, device="cuda") * 0.03).to(torch.bfloat16)
     bias = torch.randn(D, generator=g, device="cuda") * 0.1
     resid = torch.randn((M, D), generator=g, device="cuda") * 2 + 0.3
-    out, xb, part = _producer(A, W, bias, resid)
+    gamma = 1 + 0.3 * torch.randn(D, generator=g, device="cuda")
+    out, xb, part = _producer(A, W, bias, resid, gamma)
     ref = op_gemm(A, W, 3, bias=bias, resid=resid, out_dtype=torch.float32, variant=13)       # the default residual kernel
     assert torch.equal(out, ref)
-    assert torch.equal(xb, out.to(torch.bfloat16))
+    assert torch.equal(xb, (out * gamma).to(torch.bfloat16))
     cols = out.double().view(M, D // 96, 96)
     torch.testing.assert_close(part[..., 0].double(), cols.sum(2), atol=2e-3, rtol=1e-5)
     torch.testing.assert_close(part[..., 1].double(), (cols * cols).sum(2), atol=2e-2, rtol=1e-5)
@@ -122,19 +120,19 @@ def test_consuming_gemm_equals_layernorm_then_gemm(epi, N, M):
     xn = op_norm(0, x, gamma, beta, 1e-6)
     want = op_gemm(xn, W, epi, bias=bias, variant=12).float()
     # folded: raw bf16 rows, scaled weights, per-row (rstd, -mean rstd)
-    W2, c1, c2 = _fold_weights(W, gamma, beta, bias)
+    c1, c2 = _fold_weights(W, gamma, beta, bias)
     cols = x.double().view(M, 12, 96)
     ab = _stats(torch.stack([cols.sum(2), (cols * cols).sum(2)], dim=2).float(), D, 1e-6)
-    xb, abp = pad_rows(x.to(torch.bfloat16)), pad_rows(ab)
+    xb, abp = pad_rows((x * gamma).to(torch.bfloat16)), pad_rows(ab)
     out = torch.zeros((xb.shape[0], N), dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.vr_op_gemm_ln(0, P(xb), D, P(W2), D, M, N, D, epi, P(c2), None, P(out), N, None, 0, None, 0, P(abp), P(c1), 0, 0.0, None))
+    _lib.check(lib.vr_op_gemm_ln(0, P(xb), D, P(W), D, M, N, D, epi, P(c2), None, P(out), N, None, 0, None, None, 0, P(abp), P(c1), 0, 0.0, None))
     torch.cuda.synchronize()
     got = out[:M].float()
     # the form that computes (a, b) itself from the partial sums (fp32): the same outputs to bf16 rounding
     partp = torch.zeros((xb.shape[0] + 1, 12, 2), device="cuda")
     partp[:M] = torch.stack([cols.sum(2), (cols * cols).sum(2)], dim=2).float()
     out3 = torch.zeros_like(out)
-    _lib.check(lib.vr_op_gemm_ln(0, P(xb), D, P(W2), D, M, N, D, epi, P(c2), None, P(out3), N, None, 0, P(partp), 12, None, P(c1), D, 1e-6, None))
+    _lib.check(lib.vr_op_gemm_ln(0, P(xb), D, P(W), D, M, N, D, epi, P(c2), None, P(out3), N, None, 0, None, P(partp), 12, None, P(c1), D, 1e-6, None))
     torch.cuda.synchronize()
     got3 = out3[:M].float()
     assert float((got3 - got).abs().max()) <= 2 ** -7 * float(got.abs().max()), float((got3 - got).abs().max())
@@ -144,7 +142,7 @@ def test_consuming_gemm_equals_layernorm_then_gemm(epi, N, M):
         ref = torch.nn.functional.gelu(ref)
     scale = float(ref.abs().max())
     err_default, err_fold = float((want.double() - ref).abs().max()), float((got.double() - ref).abs().max())
-    assert err_fold < max(2.0 * err_default, 4e-3 * scale), (err_fold, err_default, scale)
+    assert err_fold < max(1.5 * err_default, 4e-3 * scale), (err_fold, err_default, scale)
     assert float((got[:, n_real:]).abs().max()) == 0.0 if n_real < N else True
 
 

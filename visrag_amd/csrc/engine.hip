@@ -30,8 +30,8 @@ extern "C" int vr_device_count(int* count) {
 
 struct VitBlock {
     Vec n1w, n1b, n2w, n2b; Linear qkv, proj, fc1, fc2;
-    // LayerNorm folded into the GEMM behind it (ln_fold; kernels.h: launch_gemm256w_ln): W' = gamma o W with b = c2, and c1
-    Linear qkv_f, fc1_f; Vec qkv_c1, fc1_c1;
+    // LayerNorm folded into the GEMM behind it (ln_fold; kernels.h: launch_gemm256w_ln): c1 = W gamma, c2 = bias + W beta
+    Vec qkv_c1, qkv_c2, fc1_c1, fc1_c2;
 };
 struct DecLayer {
     Vec ln1, ln2; Linear qkv, o, gu, down; int parts_qkv = 0, parts_gu = 0;
@@ -184,7 +184,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
         fl(m->patch); fl(m->r_kvproj); fl(m->r_kv); fl(m->r_out); fl(m->r_proj);
         for (auto& b : m->blocks) {
             fl(b.qkv); fl(b.proj); fl(b.fc1); fl(b.fc2); b.n1w.v.free(); b.n1b.v.free(); b.n2w.v.free(); b.n2b.v.free();
-            fl(b.qkv_f); fl(b.fc1_f); b.qkv_c1.v.free(); b.fc1_c1.v.free();
+            b.qkv_c1.v.free(); b.qkv_c2.v.free(); b.fc1_c1.v.free(); b.fc1_c2.v.free();
         }
         for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); fl(l.qkv_lo); fl(l.o_lo); fl(l.gu_lo); fl(l.down_lo); l.ln1.v.free(); l.ln2.v.free(); }
         for (Vec* v : {&m->vit_nw, &m->vit_nb, &m->r_lnq_w, &m->r_lnq_b, &m->r_lnkv_w, &m->r_lnkv_b, &m->r_lnpost_w, &m->r_lnpost_b, &m->final_norm}) v->v.free();
@@ -585,22 +585,20 @@ extern "C" int vr_model_finalize(vr_model_t m) {
         }
     }
     if (m->ln_fold) {
-        // W' = gamma o W (bf16), c1 = row sums of W', c2 = bias + W beta: block l's norm2 -> fc1, and norm1 -> qkv for l >= 1
+        // c1 = W gamma, c2 = bias + W beta: block l's norm2 -> fc1, and norm1 -> qkv for l >= 1
         // (block 0's norm1 follows the patch embedding, which is not a residual GEMM: it stays a LayerNorm launch)
-        auto fold = [&](const Linear& L, const Vec& g, const Vec& b, Linear& F, Vec& c1) -> int {
-            F.n = L.n; F.k = L.k; F.n_pad = L.n_pad; F.k_pad = L.k_pad; F.has_w = true; F.has_b = true;
-            VRCHK(F.w.alloc((size_t)L.n_pad * L.k_pad * 2));
-            VRCHK(F.b.alloc((size_t)L.n_pad * 4));
+        auto fold = [&](const Linear& L, const Vec& g, const Vec& b, Vec& c1, Vec& c2) -> int {
             VRCHK(c1.v.alloc((size_t)L.n_pad * 4));
-            c1.ok = true;
+            VRCHK(c2.v.alloc((size_t)L.n_pad * 4));
+            c1.ok = c2.ok = true;
             HIPCHK(launch_ln_fold_weights(L.w.p, L.n_pad, L.k, L.k_pad, g.v.as<float>(), b.v.as<float>(), L.has_b ? L.b.as<float>() : nullptr,
-                                          F.w.p, c1.v.as<float>(), F.b.as<float>(), 0));
+                                          c1.v.as<float>(), c2.v.as<float>(), 0));
             return VR_OK;
         };
         for (int n = 0; n < c.vit_depth; ++n) {
             VitBlock& b = m->blocks[n];
-            if (n > 0) VRCHK(fold(b.qkv, b.n1w, b.n1b, b.qkv_f, b.qkv_c1));
-            VRCHK(fold(b.fc1, b.n2w, b.n2b, b.fc1_f, b.fc1_c1));
+            if (n > 0) VRCHK(fold(b.qkv, b.n1w, b.n1b, b.qkv_c1, b.qkv_c2));
+            VRCHK(fold(b.fc1, b.n2w, b.n2b, b.fc1_c1, b.fc1_c2));
         }
         HIPCHK(hipDeviceSynchronize());
     }
@@ -734,10 +732,12 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     // a LayerNorm runs on those rows with pre-scaled weights and applies (rstd, -mean rstd) per row in its epilogue
     const bool fold = m->ln_fold != 0 && (size_t)pad256l(M) * (size_t)std::max(m->Fp, ldqkv) * 2 < (1ull << 31);   // (gemm256w_fits: 32-bit LDS-DMA offsets)
     const int ln_parts = 2 * (D / 192);
-    auto fold_emit = [&](GemmArgs& a) { a.ln_x = m->w_xn.p; a.ln_ldx = Dp; a.ln_part = m->w_lnpart.as<float>(); a.ln_parts = ln_parts; };
+    auto fold_emit = [&](GemmArgs& a, const Vec& gamma) {       // gamma: the weight of the LayerNorm that follows
+        a.ln_x = m->w_xn.p; a.ln_ldx = Dp; a.ln_gamma = gamma.v.as<float>(); a.ln_part = m->w_lnpart.as<float>(); a.ln_parts = ln_parts;
+    };
     const bool fold_stats = m->ln_fold == 1;      // a statistics launch; else the consuming GEMM's workgroups compute their rows' themselves
-    auto fold_use = [&](GemmArgs& a, const Vec& c1) {
-        a.ln_c1 = c1.v.as<float>();
+    auto fold_use = [&](GemmArgs& a, const Vec& c1, const Vec& c2) {
+        a.ln_c1 = c1.v.as<float>(); a.bias = c2.v.as<float>();
         if (fold_stats) a.ln_ab = m->w_lnab.as<float>();
         else { a.ln_part = m->w_lnpart.as<float>(); a.ln_parts = ln_parts; a.ln_dim = D; a.ln_eps = c.vit_ln_eps; }
     };
@@ -748,8 +748,8 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         else if (fold_stats) HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
         VRCHK(prof_begin(m, VR_PROF_VIT_QKV, s));
         if (fold_qkv) {
-            GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv_f, M, m->w_qkv.p, ldqkv);
-            fold_use(a, b.qkv_c1);
+            GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv);
+            fold_use(a, b.qkv_c1, b.qkv_c2);
             HIPCHK(launch_gemm256w_ln(a, EPI_BF16, s));
         } else { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_QKV, 2.0 * M * D * 3 * D, s));
@@ -767,7 +767,7 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         VRCHK(prof_begin(m, VR_PROF_VIT_PROJ, s));
         {
             GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h;
-            if (fold) { fold_emit(a); HIPCHK(launch_gemm256w_ln(a, EPI_RESID, s)); }
+            if (fold) { fold_emit(a, b.n2w); HIPCHK(launch_gemm256w_ln(a, EPI_RESID, s)); }
             else HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
         }
         VRCHK(prof_end(m, VR_PROF_VIT_PROJ, 2.0 * M * D * D, s));
@@ -775,15 +775,15 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         else if (fold_stats) HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC1, s));
         if (fold) {
-            GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1_f, M, m->w_mlp.p, m->Fp);
-            fold_use(a, b.fc1_c1);
+            GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp);
+            fold_use(a, b.fc1_c1, b.fc1_c2);
             HIPCHK(launch_gemm256w_ln(a, EPI_GELU, s));
         } else { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_FC1, 2.0 * M * D * m->F, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC2, s));
         {
             GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h;
-            if (fold && l + 1 < c.vit_depth) { fold_emit(a); HIPCHK(launch_gemm256w_ln(a, EPI_RESID, s)); }   // (the last block is followed by the post-LayerNorm launch)
+            if (fold && l + 1 < c.vit_depth) { fold_emit(a, m->blocks[l + 1].n1w); HIPCHK(launch_gemm256w_ln(a, EPI_RESID, s)); }   // (the last block is followed by the post-LayerNorm launch)
             else HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
         }
         VRCHK(prof_end(m, VR_PROF_VIT_FC2, 2.0 * M * D * m->F, s));
@@ -1623,14 +1623,14 @@ extern "C" int vr_synth_pages(int device_id, uint8_t* out, int32_t n, int32_t si
 // ------------------------------------------------ LayerNorm folded into GEMMs: op level ---
 extern "C" int vr_op_gemm_ln(int device_id, const void* A, int32_t lda, const void* W, int32_t ldw, int32_t M, int32_t N, int32_t K,
                              int32_t epilogue, const float* bias, const float* resid, void* out, int32_t ldo, void* ln_x,
-                             int32_t ln_ldx, float* ln_part, int32_t ln_parts, const float* ln_ab, const float* ln_c1, int32_t ln_dim,
-                             float ln_eps, void* stream) {
+                             int32_t ln_ldx, const float* ln_gamma, float* ln_part, int32_t ln_parts, const float* ln_ab, const float* ln_c1,
+                             int32_t ln_dim, float ln_eps, void* stream) {
     if (!A || !W || !out) return fail(VR_ERR_INVALID, "NULL argument");
     if (M <= 0 || K % 64 || N % 128) return fail(VR_ERR_INVALID, "need M > 0, N %% 128 == 0, K %% 64 == 0");
     VRCHK(set_dev(device_id));
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid; a.alpha = 1.0f;
-    a.out = out; a.ldo = ldo; a.ln_x = ln_x; a.ln_ldx = ln_ldx; a.ln_part = ln_part; a.ln_parts = ln_parts; a.ln_ab = ln_ab; a.ln_c1 = ln_c1; a.ln_dim = ln_dim; a.ln_eps = ln_eps;
+    a.out = out; a.ldo = ldo; a.ln_x = ln_x; a.ln_ldx = ln_ldx; a.ln_gamma = ln_gamma; a.ln_part = ln_part; a.ln_parts = ln_parts; a.ln_ab = ln_ab; a.ln_c1 = ln_c1; a.ln_dim = ln_dim; a.ln_eps = ln_eps;
     HIPCHK(launch_gemm256w_ln(a, epilogue, (hipStream_t)stream));
     return VR_OK;
 }
@@ -1643,9 +1643,9 @@ extern "C" int vr_op_ln_fold_stats(int device_id, const float* part, int32_t par
 }
 
 extern "C" int vr_op_ln_fold_weights(int device_id, const void* W, int32_t n_pad, int32_t k, int32_t ldw, const float* gamma,
-                                     const float* beta, const float* bias, void* W2, float* c1, float* c2, void* stream) {
+                                     const float* beta, const float* bias, float* c1, float* c2, void* stream) {
     VRCHK(set_dev(device_id));
-    HIPCHK(launch_ln_fold_weights(W, n_pad, k, ldw, gamma, beta, bias, W2, c1, c2, (hipStream_t)stream));
+    HIPCHK(launch_ln_fold_weights(W, n_pad, k, ldw, gamma, beta, bias, c1, c2, (hipStream_t)stream));
     return VR_OK;
 }
 

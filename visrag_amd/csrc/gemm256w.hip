@@ -69,7 +69,7 @@ constexpr int W_LN_AB = 1024;                              // LNF = 2: a wave's 
 constexpr int W_SMEM_BYTES_LN = W_SMEM_BYTES + 4 * W_LN_AB;
 
 // LNF (LayerNorm folded into the GEMMs around it, kernels.h: launch_gemm256w_ln; 0 in every kernel of the default path):
-//   1  EPI_RESID producer: next to the fp32 result a bf16 copy of it (ln_x) and, per row and wave column range, the partial
+//   1  EPI_RESID producer: next to the fp32 result x its rows as bf16(x o gamma) (ln_x) and, per row and wave column range, the partial
 //      (sum, sum of squares) of the stored values (ln_part);
 //   2  EPI_BF16 / EPI_GELU consumer: acc <- a[row] * acc + b[row] * c1[col] before the usual epilogue (bias = c2);
 //   3  the same, (a, b) = (rstd, -mean rstd) computed here from the producer's partial sums (fp32), no statistics launch.
@@ -151,7 +151,7 @@ hipError_t launch_gemm256w_ln(const GemmArgs& a, int epi, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.rowmap || a.rowbias) return hipErrorInvalidValue;
     if (epi == EPI_RESID) {
-        if (!a.ln_x || !a.ln_part || a.N % 192 || a.ln_parts != (a.N / 192) * 2 || !a.resid || (a.ln_ldx & 3)) return hipErrorInvalidValue;
+        if (!a.ln_x || !a.ln_part || !a.ln_gamma || a.N % 192 || a.ln_parts != (a.N / 192) * 2 || !a.resid || (a.ln_ldx & 3)) return hipErrorInvalidValue;
         return launch_wp_ln<EPI_RESID, false, 6, 1>(a, s);
     }
     if (epi == EPI_BF16 || epi == EPI_GELU) {

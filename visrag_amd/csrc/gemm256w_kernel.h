@@ -260,6 +260,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(nb0 + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                [[maybe_unused]] f32x4 ln_g[LNF == 1 ? NJ : 1];          // LNF = 1: the following LayerNorm's weight for this lane's columns
+                if constexpr (LNF == 1) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) ln_g[j] = *reinterpret_cast<const f32x4*>(p.ln_gamma + min(nb0 + j * 16 + fq * 4, p.N - 4));
+                }
                 [[maybe_unused]] float ln_s1[4][MI], ln_s2[4][MI];          // LNF = 1: this lane's share of the row sums (rows (sg, i), its 4-column groups)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                 const f32x4 vv = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
                                 if (m < p.M && n < p.N) {
                                     *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = vv;
-                                    *reinterpret_cast<bf16x4*>((bf16_t*)p.ln_x + (size_t)m * p.ln_ldx + n) = __builtin_convertvector(vv, bf16x4);
+                                    *reinterpret_cast<bf16x4*>((bf16_t*)p.ln_x + (size_t)m * p.ln_ldx + n) = __builtin_convertvector(vv * ln_g[h * NF + j], bf16x4);
                                     ln_s1[sg][i] += (vv[0] + vv[1]) + (vv[2] + vv[3]);
                                     ln_s2[sg][i] += (vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3]);
                                 }

@@ -1,9 +1,11 @@
 // LayerNorm folded into the GEMMs around it — the small kernels (the GEMM side is gemm256w.hip, LNF = 1 / 2).
 //
-//   LN(x) W^T + bias = rstd (x W'^T) - rstd mean c1 + c2,    W' = gamma o W,  c1[n] = sum_k W'[n][k],  c2 = bias + W beta
+//   LN(x) W^T + bias = rstd ((x o gamma) W^T) - rstd mean c1 + c2,    c1[n] = sum_k gamma[k] W[n][k],  c2 = bias + W beta
 //
 // (SigLIP blocks: vision_transformer.py:92-96 `x + attn(norm1(x))`, `x + mlp(norm2(x))`.)  The residual GEMM that produces
-// x leaves, per row and per 96-column half tile it owns, the partial (sum, sum of squares) of the fp32 values it stored;
+// x leaves bf16(x o gamma) (gamma applied BEFORE the one rounding: scaling the weights instead would round twice — the
+// CPU emulation tests/test_cpu_ln_fold_numerics.py puts that at 1.44x the default route's error, this form at 1.08x) and, per row
+// and per 96-column half tile it owns, the partial (sum, sum of squares) of the fp32 values it stored;
 // ln_fold_stats_kernel combines a row's partials IN INDEX ORDER (fixed order: results do not depend on which
 // workgroup finished first) in double and writes (a, b) = (rstd, -mean rstd), which the consuming GEMM's epilogue
 // applies as a * acc + b * c1[n] + c2[n].  Roofline: nothing here is worth one (3 MB per launch).
@@ -37,22 +39,15 @@ hipError_t launch_ln_fold_stats(const float* part, int parts, int rows, int dim,
 // one workgroup per weight row n
 __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const bf16_t* __restrict__ W, int k, int ldw, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ bias,
-                                                             bf16_t* __restrict__ W2, float* __restrict__ c1, float* __restrict__ c2) {
+                                                             float* __restrict__ c1, float* __restrict__ c2) {
     __shared__ double red[2][256];
     const int n = blockIdx.x, tid = threadIdx.x;
     const bf16_t* w = W + (size_t)n * ldw;
-    bf16_t* w2 = W2 + (size_t)n * ldw;
     double s1 = 0.0, s2 = 0.0;
-    for (int kk = tid; kk < ldw; kk += 256) {
-        if (kk < k) {
-            const float x = bf2f(w[kk]);
-            const bf16_t y = f2bf(x * gamma[kk]);
-            w2[kk] = y;
-            s1 += (double)bf2f(y);                              // (the ROUNDED product: what the GEMM multiplies the row mean into)
-            s2 += (double)beta[kk] * (double)x;
-        } else {
-            w2[kk] = w[kk];                                     // (K padding: zeros)
-        }
+    for (int kk = tid; kk < k; kk += 256) {
+        const double x = (double)bf2f(w[kk]);
+        s1 += (double)gamma[kk] * x;
+        s2 += (double)beta[kk] * x;
     }
     red[0][tid] = s1; red[1][tid] = s2;
     __syncthreads();
@@ -67,10 +62,10 @@ __global__ __launch_bounds__(256) void ln_fold_weight_kernel(const bf16_t* __res
 }
 
 hipError_t launch_ln_fold_weights(const void* W, int n_pad, int k, int ldw, const float* gamma, const float* beta, const float* bias,
-                                  void* W2, float* c1, float* c2, hipStream_t s) {
+                                  float* c1, float* c2, hipStream_t s) {
     if (n_pad <= 0) return hipSuccess;
-    if (!W || !gamma || !beta || !W2 || !c1 || !c2 || k <= 0 || ldw < k) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_fold_weight_kernel, dim3(n_pad), dim3(256), 0, s, (const bf16_t*)W, k, ldw, gamma, beta, bias, (bf16_t*)W2, c1, c2);
+    if (!W || !gamma || !beta || !c1 || !c2 || k <= 0 || ldw < k) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_fold_weight_kernel, dim3(n_pad), dim3(256), 0, s, (const bf16_t*)W, k, ldw, gamma, beta, bias, c1, c2);
     return hipGetLastError();
 }
 
