@@ -265,6 +265,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) ln_g[j] = *reinterpret_cast<const f32x4*>(p.ln_gamma + min(nb0 + j * 16 + fq * 4, p.N - 4));
                 }
+                constexpr int LN_PITCH = 112;            // bytes per staged row: 96 of data, 16-byte aligned chunks
+                typedef __attribute__((address_space(3))) char* ln_lds_p;
+                [[maybe_unused]] const ln_lds_p ln_st = (ln_lds_p)VR_LDS(wl0);
                 [[maybe_unused]] float ln_s1[4][MI], ln_s2[4][MI];          // LNF = 1: this lane's share of the row sums (rows (sg, i), its 4-column groups)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -292,9 +295,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
                             if constexpr (LNF == 1) {
                                 const f32x4 vv = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
+                                // the bf16 row goes through this wave's LDS slice (below): a direct store would be 8 bytes per
+                                // lane, 32-byte segments — measured (round 4, first run): proj 3.31 -> 4.11, fc2 7.84 -> 8.85 ms per step
+                                *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(ln_st + (i * 16 + fr) * LN_PITCH + j * 32 + fq * 8) =
+                                    __builtin_convertvector(vv * ln_g[h * NF + j], bf16x4);
                                 if (m < p.M && n < p.N) {
                                     *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = vv;
-                                    *reinterpret_cast<bf16x4*>((bf16_t*)p.ln_x + (size_t)m * p.ln_ldx + n) = __builtin_convertvector(vv * ln_g[h * NF + j], bf16x4);
                                     ln_s1[sg][i] += (vv[0] + vv[1]) + (vv[2] + vv[3]);
                                     ln_s2[sg][i] += (vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3]);
                                 }
@@ -303,6 +309,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                     *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
                             }
 #endif
+                        }
+                    }
+                    if constexpr (LNF == 1) {
+                        // read the piece back row-wise (a wave's LDS operations execute in order): 32 rows x 96 bytes = 192 chunks of 16 bytes
+                        static_assert(NF == 3, "96-byte row segments");
+                        u32x4 d[3];
+#pragma unroll
+                        for (int it = 0; it < 3; ++it) {
+                            const int idx = it * 64 + lane, row = idx / 6, ch = idx - row * 6;
+                            d[it] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(ln_st + row * LN_PITCH + ch * 16);
+                        }
+#pragma unroll
+                        for (int it = 0; it < 3; ++it) {
+                            const int idx = it * 64 + lane, row = idx / 6, ch = idx - row * 6;
+                            const int m = mrow0 + sg * 32 + row, n = nb0 + h * (16 * NF) + ch * 8;
+                            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>((bf16_t*)p.ln_x + (size_t)m * p.ln_ldx + n) = d[it];
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -324,6 +346,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         }
                 }
             }
+        }
+        // LNF = 2 / 3: c1 and c2 of this wave's columns, requested once for the whole tile (a request per piece — 0.5 us of latency
+        // each behind the scheduling barriers — and a separate bias pass cost qkv + 0.36, fc1 + 0.55 ms per step in the first run)
+        [[maybe_unused]] f32x4 ln_c1v[LNF >= 2 ? NJ : 1], ln_c2v[LNF >= 2 ? NJ : 1];
+        [[maybe_unused]] GemmArgs pq = p;
+        if constexpr (LNF >= 2) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = min(nb0 + j * 16 + fq * 4, p.N - 4);
+                ln_c1v[j] = *reinterpret_cast<const f32x4*>(p.ln_c1 + n);
+                ln_c2v[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            pq.bias = nullptr;                          // (added here, with the correction)
         }
         if (!plain_resid) {
 #pragma unroll
@@ -376,19 +411,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // acc <- a[row] acc + b[row] c1[col]   (then bias = c2 and the activation, below)
                     typedef const __attribute__((address_space(3))) f32x2* ab_p;
                     const ab_p abl = (ab_p)VR_LDS(smem + W_SMEM_BYTES + (LNF == 2 ? wave * W_LN_AB : wm * 128 * 8));
-                    f32x4 c1v[NF];
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) c1v[j] = *reinterpret_cast<const f32x4*>(p.ln_c1 + min(nb + j * 16 + fq * 4, p.N - 4));
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
                         const f32x2 ab = abl[sg * 32 + i * 16 + fr];
 #pragma unroll
-                        for (int j = 0; j < NF; ++j) acc[i][j] = acc[i][j] * ab[0] + c1v[j] * ab[1];
+                        for (int j = 0; j < NF; ++j) acc[i][j] = acc[i][j] * ab[0] + (ln_c1v[h * NF + j] * ab[1] + ln_c2v[h * NF + j]);
                     }
                 }
                 if constexpr (NF == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE)) {
                     if constexpr (PLAIN) {
-                        gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mr, nb, lane, wl0);
+                        gemm_epilogue_tile_lds_plain<EPI, MI>(acc, LNF >= 2 ? pq : p, mr, nb, lane, wl0);
                         done = true;
                     } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
                         gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl0);
