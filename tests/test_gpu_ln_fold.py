@@ -1,6 +1,8 @@
 """-m gpu, OFF unless VISRAG_TEST_LN_FOLD=1: the experimental folding of the ViT blocks' LayerNorms into the GEMMs around
-them (include/visrag_hip.h: vr_op_gemm_ln; VR_VIT_LN_FOLD=1 at vr_model_create).  Written in round 4 without a GPU at
-hand — the default path does not run any of this, and these tests are skipped until the code has been run once:
+them (include/visrag_hip.h: vr_op_gemm_ln; VR_VIT_LN_FOLD=1 / 2 at vr_model_create).  Written at the end of round 4; the
+first form passed the nine op-level tests on its first run (profiles/r04_lnfold_first_tests.log) and the encoder agrees with
+the default route to cosine 0.99999 (tools/ab_ln_fold.py), but the kernels changed once more afterwards (bf16 rows staged
+through LDS, c1 / c2 hoisted) with no GPU time left to re-run these — so they stay behind the switch with the feature:
 
   * vr_op_ln_fold_weights against torch (c1 = W gamma, c2 = bias + W beta);
   * the residual GEMM with the extra outputs: fp32 result BIT-IDENTICAL to the default residual kernel, bf16 rows ==
