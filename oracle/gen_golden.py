@@ -6,6 +6,9 @@ deterministic synthetic checkpoint (visrag_amd/synth.py) and stand-in tokenizer.
     python oracle/gen_golden.py --full     # + full MiniCPM-V-2.0 dims, 2 pages + 2 queries (minutes)
     python oracle/gen_golden.py --config1  # ONLY BASELINE config 1: full dims, 64 pages 448^2 (bs 16) + 16 queries
                                            # through the reference encode + retrieve (top-3), ~10 min on 8 cores
+    python oracle/gen_golden.py --config1xl  # the same chain at 512 pages + the reference's OWN input images (cat.jpeg,
+                                           # dog.jpg, the two 0.parquet pages: copied to tests/golden/inputs/) x 512 + 2
+                                           # queries, top-10 (~25 min on 8 cores; resumable: partial state under /tmp)
 
 Runs only in the build container (the reference tree does not travel to the GPU box);
 the resulting fixtures are committed.
@@ -158,15 +161,143 @@ def config1(n_pages=64, n_queries=16, bs=16, k=3):
           "median gap", float(np.median(gap)), "threads", torch.get_num_threads())
 
 
+REF_IMAGES = (("cat", "visrag_scripts/demo/retriever/test_image/cat.jpeg"),      # 2160x1790 -> source + 3x3 slices
+              ("dog", "visrag_scripts/demo/retriever/test_image/dog.jpg"))       # 1072x670  -> source + 2x2 slices
+REF_PARQUET = "examples/training_data/0.parquet"                                   # two InfoVQA pages + their queries
+
+
+def export_reference_inputs():
+    """The reference's own input fixtures ("worth reusing"), copied byte for byte under
+    tests/golden/inputs/ (input DATA, not source): the demo's two test images and the two page images + queries of
+    examples/training_data/0.parquet.  Returns [(doc id, file name)], [query text]."""
+    import json
+    import shutil
+    import pyarrow.parquet as pq
+    dst = os.path.join(GOLD, "inputs")
+    os.makedirs(dst, exist_ok=True)
+    docs = []
+    for name, rel in REF_IMAGES:
+        fn = name + os.path.splitext(rel)[1]
+        shutil.copyfile(os.path.join(ref_harness.REFERENCE_ROOT, rel), os.path.join(dst, fn))
+        os.chmod(os.path.join(dst, fn), 0o644)
+        docs.append((name, fn))
+    rows = pq.read_table(os.path.join(ref_harness.REFERENCE_ROOT, REF_PARQUET)).to_pylist()
+    queries = []
+    for i, r in enumerate(rows):
+        raw = r["image"]["bytes"]
+        ext = ".png" if raw[:4] == b"\x89PNG" else ".jpg"
+        fn = f"infovqa_{i}{ext}"
+        with open(os.path.join(dst, fn), "wb") as f:
+            f.write(raw)
+        docs.append((f"infovqa_{i}", fn))
+        queries.append(r["query"])
+    with open(os.path.join(dst, "manifest.json"), "w") as f:
+        json.dump({"docs": docs, "queries": queries,
+                   "from": [rel for _, rel in REF_IMAGES] + [REF_PARQUET]}, f, indent=1)
+    return docs, queries
+
+
+def config1xl(n_pages=512, n_queries=512, bs=16, k=10, state="/tmp/config1xl_state.npz"):
+    """Row c / verdict r4 item 2: the encode -> retrieve chain of config 1 at a size where "identical top-k doc ids"
+    means something: 512 structured synthetic pages 448x448 (pages 0..511 of synth_pages seed 0; the first 64 are
+    config 1's) + the reference's own four input images (sliced pages: 10 / 5 / ... images each) form a 516-document
+    corpus; 512 synthetic queries + the two parquet queries; everything through the reference's DRModelForInference
+    (CPU fp32, batches of 16, inference.py:53-172) and its distributed_parallel_retrieve top-10
+    (dense_retriever.py:13-97) over 4 pickle shards.  The fixture keeps both embedding matrices, the ranked top-(k+1)
+    and the rank-k / rank-(k+1) gap per query."""
+    import time
+    from PIL import Image
+    cfg = full_config()
+    dr = ref_harness.build_reference_dr_model(cfg, synth_state_dict(cfg, 0))
+    tok = StandInTokenizer(cfg.vocab_size)
+    docs, ref_queries = export_reference_inputs()
+    st = dict(np.load(state)) if os.path.exists(state) else {}
+    P = list(st["P"]) if "P" in st else []
+    secs = float(st["secs"]) if "secs" in st else 0.0
+    with torch.no_grad():
+        while len(P) < n_pages:
+            lo = len(P)
+            t0 = time.time()
+            imgs = [Image.fromarray(a) for a in synth_pages(min(bs, n_pages - lo), size=448, seed=0, first=lo)]
+            o = dr(passage={"id": [str(i) for i in range(lo, lo + len(imgs))], "text": [""] * len(imgs), "image": imgs},
+                   tokenizer=tok, max_inp_length=2048)
+            P.extend(o.p_reps.numpy().astype(np.float32))
+            secs += time.time() - t0
+            np.savez(state, P=np.stack(P), secs=secs)
+            print(f"pages {len(P)}/{n_pages}  {secs:.0f}s", flush=True)
+        t0 = time.time()
+        R = []
+        for name, fn in docs:                                   # one sliced page per call, as demo.py:44-58 does
+            im = Image.open(os.path.join(GOLD, "inputs", fn)).convert("RGB")
+            o = dr(passage={"id": [name], "text": [""], "image": [im]}, tokenizer=tok, max_inp_length=2048)
+            R.append(o.p_reps.numpy().astype(np.float32)[0])
+            print(f"reference image {name} {im.size}  {time.time() - t0:.0f}s", flush=True)
+        t_real = time.time() - t0
+        queries = [QUERY_PREFIX + q for q in synth_queries(n_queries, seed=0)] + [QUERY_PREFIX + q for q in ref_queries]
+        t0 = time.time()
+        Q = []
+        for lo in range(0, len(queries), bs):
+            qs = queries[lo:lo + bs]
+            o = dr(query={"id": [str(i) for i in range(lo, lo + len(qs))], "text": qs, "image": [None] * len(qs)},
+                   tokenizer=tok, max_inp_length=512)
+            Q.append(o.q_reps.numpy().astype(np.float32))
+            print(f"queries {lo + len(qs)}/{len(queries)}  {time.time() - t0:.0f}s", flush=True)
+        t_q = time.time() - t0
+    P = np.concatenate([np.stack(P), np.stack(R)]).astype(np.float32)
+    Q = np.concatenate(Q).astype(np.float32)
+    doc_ids = [f"doc{j}" for j in range(n_pages)] + [n for n, _ in docs]
+    res, trec = reference_retrieve_ids(P, Q, doc_ids, n_shards=4, k=k)
+    S = Q @ P.T
+    order = np.argsort(-S, axis=1, kind="stable")[:, :k + 1]
+    top_scores = np.take_along_axis(S, order, 1)
+    gap = top_scores[:, k - 1] - top_scores[:, k]
+    for qi in range(len(Q)):                                   # the reference's result holds the brute-force top-k
+        for j in range(k):
+            assert abs(res[f"q{qi}"][doc_ids[order[qi, j]]] - top_scores[qi, j]) < 1e-6
+    np.savez_compressed(os.path.join(GOLD, "config1xl_full.npz"), p_reps=P, q_reps=Q,
+                        top_ids=order.astype(np.int32), top_scores=top_scores.astype(np.float32), gap=gap.astype(np.float32),
+                        doc_ids=np.array(doc_ids), n_pages=n_pages, n_ref_images=len(docs), n_queries=n_queries,
+                        n_ref_queries=len(ref_queries), k=k, page_seed=0, query_seed=0,
+                        ref_seconds=np.array([secs, t_real, t_q], dtype=np.float32), ref_threads=torch.get_num_threads())
+    print("config1xl_full: pages/s", n_pages / secs, "queries/s", len(queries) / t_q, "strict (gap > 2e-3):",
+          int((gap > 2e-3).sum()), "of", len(gap), "median gap", float(np.median(gap)), "threads", torch.get_num_threads())
+
+
+def reference_retrieve_ids(p_reps, q_reps, doc_ids, n_shards, k):
+    """reference_retrieve with caller-supplied document ids."""
+    ref_harness.install_shims()
+    from openmatch.retriever.dense_retriever import distributed_parallel_retrieve
+    from openmatch.utils import save_as_trec
+    with tempfile.TemporaryDirectory() as d:
+        n = len(p_reps)
+        per = (n + n_shards - 1) // n_shards
+        for s in range(n_shards):
+            lo, hi = s * per, min(n, (s + 1) * per)
+            with open(os.path.join(d, f"embeddings.corpus.rank.0.{lo}-{hi}"), "wb") as f:
+                pickle.dump((p_reps[lo:hi], list(doc_ids[lo:hi])), f, protocol=4)
+        with open(os.path.join(d, "embeddings.query.rank.0"), "wb") as f:
+            pickle.dump((q_reps, [f"q{j}" for j in range(len(q_reps))]), f, protocol=4)
+        args = types.SimpleNamespace(output_dir=d, process_index=0, device="cpu")
+        res = distributed_parallel_retrieve(args, k)
+        trec = os.path.join(d, "out", "test.0.trec")
+        save_as_trec(res, trec)
+        with open(trec) as f:
+            trec_text = f.read()
+    return res, trec_text
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--config1", action="store_true")
+    ap.add_argument("--config1xl", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_grad_enabled(False)
     if a.config1:
         return config1()
+    if a.config1xl:
+        return config1xl()
 
     # ---- tiny dims: 4 single-slice pages (112x112), 2 sliced pages, 3 queries ----------
     cfg = tiny_config()

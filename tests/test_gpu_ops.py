@@ -187,6 +187,54 @@ def test_attention(hd, heads, lens, causal):
             np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("lens", [[1024], [1024, 1000, 777, 256], [512, 300, 33], [256], [1280, 1], [960, 1023, 65]])
+def test_attention_vit_one_wave_per_simd(lens):
+    """attention_w.hip (head_dim 72, non-causal, query tiles of 256 rows, the hand-ordered stream): full tiles, ragged key
+    counts (masked last tile, junk halves), sequences shorter than one query tile next to long ones."""
+    hd, heads = 72, 3
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    T, W = int(cu[-1]), heads * hd
+    qkv = _bf(_rand((T, 3 * W), 70 + len(lens), 1.0))
+    d = qkv.to(DEV)
+    scale = hd ** -0.5
+    out = op_attention(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], cu.to(DEV), cu.to(DEV), heads, hd, max(lens), False, False,
+                       scale, T).float().cpu()
+    for b in range(len(lens)):
+        lo, hi = int(cu[b]), int(cu[b + 1])
+        for h in range(heads):
+            ref = _ref_attn(qkv[lo:hi, h * hd:(h + 1) * hd], qkv[lo:hi, W + h * hd:W + (h + 1) * hd],
+                            qkv[lo:hi, 2 * W + h * hd:2 * W + (h + 1) * hd], False, scale)
+            np.testing.assert_allclose(out[lo:hi, h * hd:(h + 1) * hd].numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("case", ["late_spikes", "rising", "all_negative", "huge_first"])
+def test_attention_vit_running_maximum_is_raised_correctly(case):
+    """The rare block of attention_w.hip that raises a row's running maximum between two periods: O, the packed P not yet
+    multiplied and the scores already computed against the old maximum must each be rescaled exactly once
+    (cdna guide T13).  Inputs that force it in early, middle and late tiles, for single rows and for all rows at once."""
+    hd, L = 72, 1024
+    q = _rand((L, hd), 40); k = _rand((L, hd), 41); v = _rand((L, hd), 42)
+    if case == "late_spikes":            # single keys dominate single rows, in tiles 3, 9 and 15 and inside both halves of a tile
+        for row, key, gain in ((10, 250, 8.0), (300, 600, 12.0), (301, 633, 6.0), (777, 1000, 10.0), (1023, 1023, 9.0), (0, 40, 7.0)):
+            k[key] = q[row] * gain
+    elif case == "rising":               # every row's maximum grows tile after tile
+        k = k * torch.linspace(0.2, 6.0, L)[:, None]
+        k = q.mean(0, keepdim=True) * torch.linspace(0.0, 3.0, L)[:, None] + k
+    elif case == "all_negative":         # scores far below zero everywhere (the first half sets a negative maximum)
+        k = -q.mean(0, keepdim=True).expand(L, hd) * 4.0 + 0.1 * k
+        q = q + 2.0 * q.mean(0, keepdim=True)
+    else:                                # the first key towers over everything after it
+        k[0] = q.mean(0) * 30.0
+    qkv = _bf(torch.cat([q, k, v], dim=1))
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    d = qkv.to(DEV)
+    out = op_attention(d[:, :hd], d[:, hd:2 * hd], d[:, 2 * hd:], cu.to(DEV), cu.to(DEV), 1, hd, L, False, False,
+                       hd ** -0.5, L).float().cpu()
+    ref = _ref_attn(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], False, hd ** -0.5)
+    assert torch.isfinite(out).all()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("lens,causal", [([68] * 7, True), ([68, 13, 80, 1, 16, 17, 79, 33], True), ([68, 5, 80, 48], False)])
 def test_attention_short_sequences_one_wave_each(lens, causal):
     """attention_small.hip: self-attention of packed sequences of at most 80 tokens (head_dim 64, cu_q IS cu_kv — the

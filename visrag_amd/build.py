@@ -18,18 +18,20 @@ from typing import Iterable, List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "ln_fold.hip", "gemm_skinny.hip", "gen_persist.hip", "norm.hip", "attention.hip", "attention_small.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip", "search256w.hip",
+SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "ln_fold.hip", "gemm_skinny.hip", "gen_persist.hip", "norm.hip", "attention.hip", "attention_w.hip", "attention_small.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip", "search256w.hip",
            "search_small.hip", "search_bigk.hip", "search_exact.hip", "search_band.hip", "hp_text.hip", "resize.hip", "synth.hip", "pack.hip", "engine.hip", "gen_kernels.hip", "gen.hip", "gen_vision.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: relaxed NaN handling only (infinities are honoured: masked scores are -inf).  Without it
 # every fmaxf of an MFMA result is preceded by a canonicalising v_max_f32 x, x (32 extra VALU per tile);
 # same for the clamp of the GELU epilogue (gemm*.hip: one v_max per output value).
-FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "attention_small.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nans"], "gemm192.hip": ["-fno-honor-nans"],
+FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "attention_w.hip": ["-fno-honor-nans"], "attention_small.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nans"], "gemm192.hip": ["-fno-honor-nans"],
               "gemm256w.hip": ["-fno-honor-nans"], "gen_persist.hip": ["-fno-honor-nans"]}
 # gemm256w.hip hand-allocates the accumulation registers inside asm statements; hipcc only sees them as clobbers,
 # so if it ever runs out of VGPRs there it parks the overflow in registers that hold results.  The build checks
 # the generated code: outside the kernel's own asm there must be no accumulation-register traffic at all.
-AGPR_CHECKED = {"gemm256w.hip", "search256w.hip"}
+AGPR_CHECKED = {"gemm256w.hip", "search256w.hip", "attention_w.hip"}
+# ... and whose score MFMAs are asm statements on arch VGPRs: the listing is also walked for operand hazards (mfma_operand_hazards)
+MFMA_HAZARD_CHECKED = {"attention_w.hip"}
 
 
 def lib_path(tag: str = "") -> str:
@@ -78,11 +80,80 @@ def agpr_violations(asm_text: str) -> List[str]:
     return bad
 
 
+_REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+
+
+def _regs(operand_text: str):
+    out = set()
+    for m in _REG.finditer(operand_text):
+        if m.group(1):
+            out.add((m.group(1), int(m.group(2))))
+        else:
+            out.update((m.group(3), k) for k in range(int(m.group(4)), int(m.group(5)) + 1))
+    return out
+
+
+def mfma_operand_hazards(asm_text: str, raw_states: int = 2, result_states: int = 12) -> List[str]:
+    """Files whose MFMAs are asm statements (hipcc neither pads nor orders around them): walk the listing and report
+      * a VALU / accvgpr write of a register that an MFMA within the next `raw_states` wait states reads (A, B or C), and
+      * any non-MFMA instruction that touches an MFMA's VGPR / AGPR result within `result_states` wait states of its issue
+        (an MFMA taking the whole result as its C is the accumulate chain: fine).
+    Wait states are counted conservatively: one per instruction, n + 1 for `s_nop n`, 4 for an MFMA (its issue passes)."""
+    bad: List[str] = []
+    recent_writes: List[tuple] = []          # (states ago, regs, text) of VALU writes
+    pending: List[list] = []                 # [states left, result regs, text] of MFMAs
+    for ln in asm_text.splitlines():
+        t = ln.strip()
+        if not t or t.startswith((".", ";", "//")) or t.endswith(":"):
+            if t.endswith(":") and not t.startswith(";"):
+                recent_writes, pending = [], []          # (a label: another path may join — hazards across it are not modelled)
+            continue
+        code = t.split(";", 1)[0].strip()
+        if not code:
+            continue
+        parts = code.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+        states = 1
+        if op == "s_nop":
+            states = int(args.strip() or "0", 0) + 1
+        ops = [a.strip() for a in args.split(",")]
+        if op.startswith("v_mfma"):
+            dst, srcs = _regs(ops[0]), [_regs(o) for o in ops[1:4]]
+            for ago, regs, text in recent_writes:
+                if ago < raw_states and any(regs & s_ for s_ in srcs):
+                    bad.append(f"`{text}` {ago} wait state(s) in front of `{code}`")
+            for pnd in pending:
+                whole_c = len(srcs) == 3 and srcs[2] == pnd[1]
+                if pnd[0] > 0 and not whole_c and (pnd[1] & (dst | srcs[0] | srcs[1] | (srcs[2] if len(srcs) == 3 else set()))):
+                    bad.append(f"`{code}` overlaps the result of `{pnd[2]}` {result_states - pnd[0]} wait state(s) behind it")
+            states = 4
+            new_pending = [result_states, dst, code]
+        else:
+            new_pending = None
+            touched = _regs(args)
+            for pnd in pending:
+                if pnd[0] > 0 and (pnd[1] & touched):
+                    bad.append(f"`{code}` touches the result of `{pnd[2]}` {result_states - pnd[0]} wait state(s) behind it")
+        if op.startswith("v_") and not op.startswith("v_mfma") and not op.startswith("v_cmp") and ops:
+            recent_writes.append((0, _regs(ops[0]), code))
+        recent_writes = [(a + states, r, x) for a, r, x in recent_writes if a + states < raw_states + 2]
+        for pnd in pending:
+            pnd[0] -= states
+        pending = [p_ for p_ in pending if p_[0] > 0]
+        if new_pending:
+            pending.append(new_pending)
+    return bad
+
+
 def _check_no_compiler_agprs(hipcc: str, src: str, flags: List[str]) -> None:
     r = subprocess.run([hipcc, *[f for f in flags if f != "-fPIC"], "--cuda-device-only", "-S", src, "-o", "-"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stderr[-2000:]}")
+    if os.path.basename(src) in MFMA_HAZARD_CHECKED:
+        hz = mfma_operand_hazards(r.stdout)
+        if hz:
+            raise RuntimeError(f"{os.path.basename(src)}: {len(hz)} MFMA operand hazard(s) in the generated code, first: {hz[0]}")
     bad = agpr_violations(r.stdout)
     if bad:
         raise RuntimeError(f"{os.path.basename(src)}: hipcc generated `{bad[0]}` (+{len(bad) - 1} more) outside the hand-written "

@@ -73,6 +73,12 @@ static hipError_t launch_t(const AttnArgs& a, hipStream_t s) {
 #endif
 bool attention_small_ok(const AttnArgs& a);
 hipError_t launch_attention_small(const AttnArgs& a, hipStream_t s);
+// the ViT shape on the one-wave-per-SIMD kernel with the hand-ordered stream (attention_w.hip)
+#ifndef VR_ATTN_W
+#define VR_ATTN_W 1
+#endif
+bool attention72w_ok(const AttnArgs& a);
+hipError_t launch_attention72w(const AttnArgs& a, hipStream_t s);
 
 hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (a_in.B <= 0 || a_in.max_q <= 0) return hipSuccess;
@@ -80,6 +86,7 @@ hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     const AttnArgs& a = a_in;
     // self-attention of short packed sequences (the decoder over a page's 68 tokens): a wave per (sequence, head)
     if (VR_ATTN_SMALL && attention_small_ok(a)) return launch_attention_small(a, s);
+    if (VR_ATTN_W && attention72w_ok(a)) return launch_attention72w(a, s);
     // q-fragments per wave: 2 (32 rows) for long sequences; PIPE 0 (single slot, no pipeline prologue) is the
     // fastest form for the one- or two-tile sequences of the decoder (68-token pages: 13.8 vs 15.7 us)
     const bool big = a.max_q > 64;
