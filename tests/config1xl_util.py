@@ -1,0 +1,98 @@
+"""Shared by tests/test_gpu_config1xl.py and bench.py's `reference_parity` leg: the encode -> retrieve chain of BASELINE
+config 1 at 512 synthetic pages + the reference's own four input images x 512 synthetic + 2 parquet queries, top-10, against
+the fixture the REFERENCE produced (oracle/gen_golden.py --config1xl: openmatch's DRModelForInference on CPU fp32, then its
+distributed_parallel_retrieve).  Nothing here reads /root/reference: inputs and outputs are the committed fixtures."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+QUERY_PREFIX = "Represent this query for retrieving relevant documents: "
+TOL = 1e-3
+
+
+def load_fixture():
+    g = np.load(os.path.join(GOLD, "config1xl_full.npz"))
+    with open(os.path.join(GOLD, "inputs", "manifest.json")) as f:
+        man = json.load(f)
+    return g, man
+
+
+def corpus_and_queries(g, man):
+    """The items the reference encoded, in its order: [{'id','text','image'}] for the corpus and for the queries."""
+    from PIL import Image
+    from visrag_amd.synth import synth_pages, synth_queries
+    n_pages, n_q = int(g["n_pages"]), int(g["n_queries"])
+    pages = synth_pages(n_pages, size=448, seed=int(g["page_seed"]))
+    corpus = [{"id": f"doc{i}", "text": "", "image": Image.fromarray(p)} for i, p in enumerate(pages)]
+    for name, fn in man["docs"]:
+        corpus.append({"id": name, "text": "", "image": Image.open(os.path.join(GOLD, "inputs", fn)).convert("RGB")})
+    texts = [QUERY_PREFIX + t for t in synth_queries(n_q, seed=int(g["query_seed"]))] + [QUERY_PREFIX + t for t in man["queries"]]
+    queries = [{"id": f"q{i}", "text": t, "image": None} for i, t in enumerate(texts)]
+    assert [c["id"] for c in corpus] == [str(x) for x in g["doc_ids"]]
+    return corpus, queries
+
+
+def parity_stats(g, P, Q, run, k=None):
+    """P [516, D], Q [514, D]: this path's embeddings in the fixture's order; run: {qid: {docid: score}} from the drop-in
+    retrieve.  Returns the numbers north_star words ("identical top-k doc IDs, cosine scores within 1e-3") — unconditional
+    and gated — and raises AssertionError where a bar is missed."""
+    k = int(g["k"]) if k is None else k
+    doc_ids = [str(x) for x in g["doc_ids"]]
+    col = {d: j for j, d in enumerate(doc_ids)}
+    Sref = g["q_reps"] @ g["p_reps"].T
+    S = Q @ P.T
+    cos_p = (P * g["p_reps"]).sum(1)
+    cos_q = (Q * g["q_reps"]).sum(1)
+    err = np.abs(S - Sref)
+    nq = len(Q)
+    identical = ordered_prefix = overlap = strict = strict_ok = equiv_ok = 0
+    worst_returned = 0.0
+    for qi in range(nq):
+        got = sorted(run[f"q{qi}"].items(), key=lambda kv: (-kv[1], kv[0]))[:k]
+        got_ids = [d for d, _ in got]
+        ref_ids = [doc_ids[j] for j in g["top_ids"][qi, :k]]
+        for d, s in got:
+            worst_returned = max(worst_returned, abs(s - Sref[qi, col[d]]))
+        identical += got_ids == ref_ids
+        overlap += len(set(got_ids) & set(ref_ids))
+        if g["gap"][qi] > 2 * TOL:                       # well separated at the cut: the SET must be the reference's
+            strict += 1
+            strict_ok += set(got_ids) == set(ref_ids)
+        kth = g["top_scores"][qi, k - 1]                 # everywhere: nothing returned lies outside the tolerance band
+        equiv_ok += all(Sref[qi, col[d]] >= kth - 2 * TOL for d in got_ids)
+    # within the top-k an ordering can only flip between neighbours closer than 2 tol: count the queries whose ORDER is
+    # the reference's wherever its neighbouring scores are further apart than that
+    for qi in range(nq):
+        got_ids = [d for d, _ in sorted(run[f"q{qi}"].items(), key=lambda kv: (-kv[1], kv[0]))[:k]]
+        ref_rank = {doc_ids[j]: r for r, j in enumerate(g["top_ids"][qi, :k])}
+        ok = True
+        for a in range(len(got_ids) - 1):
+            da, db = got_ids[a], got_ids[a + 1]
+            if da in ref_rank and db in ref_rank and ref_rank[da] > ref_rank[db]:
+                ok &= abs(Sref[qi, col[da]] - Sref[qi, col[db]]) <= 2 * TOL
+        ordered_prefix += ok
+    st = {
+        "fixture": "tests/golden/config1xl_full.npz (reference: openmatch DRModelForInference + distributed_parallel_retrieve, CPU fp32)",
+        "pages": int(g["n_pages"]), "reference_images": int(g["n_ref_images"]), "queries": nq, "k": k,
+        "min_cosine_pages": float(cos_p[: int(g["n_pages"])].min()), "min_cosine_reference_images": float(cos_p[int(g["n_pages"]):].min()),
+        "min_cosine_queries": float(cos_q.min()),
+        "max_abs_score_error": float(err.max()), "rms_score_error": float(np.sqrt((err ** 2).mean())),
+        "max_abs_error_of_returned_scores": float(worst_returned),
+        "topk_ids_identical_in_order": float(identical) / nq, "overlap_at_k": float(overlap) / (nq * k),
+        "queries_gated_strict (rank-k / k+1 gap > 2e-3)": strict, "strict_id_sets_identical": strict_ok,
+        "queries_tolerance_equivalent": equiv_ok, "queries_order_consistent_beyond_2tol": ordered_prefix,
+    }
+    st = {k_: (v.item() if hasattr(v, "item") else v) for k_, v in st.items()}
+    return st
+
+
+def assert_bars(st):
+    assert st["min_cosine_pages"] > 1 - TOL and st["min_cosine_queries"] > 1 - TOL and st["min_cosine_reference_images"] > 1 - TOL, st
+    assert st["max_abs_score_error"] < TOL, st
+    assert st["max_abs_error_of_returned_scores"] < TOL, st
+    assert st["queries_gated_strict (rank-k / k+1 gap > 2e-3)"] >= 30, st
+    assert st["strict_id_sets_identical"] == st["queries_gated_strict (rank-k / k+1 gap > 2e-3)"], st
+    assert st["queries_tolerance_equivalent"] == st["queries"], st
+    assert st["queries_order_consistent_beyond_2tol"] == st["queries"], st
