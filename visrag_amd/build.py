@@ -57,7 +57,7 @@ def _newest_header() -> float:
 _AGPR_OPERAND = re.compile(r"(?<![\w.$])a(\d+|\[\d+:\d+\])(?![\w])")
 
 
-def agpr_violations(asm_text: str) -> List[str]:
+def agpr_violations(asm_text: str, owned: Optional[range] = None) -> List[str]:
     """Instructions of a `hipcc -S` listing that touch accumulation registers outside `;;#ASMSTART ... ;;#ASMEND`:
     `v_accvgpr_*` moves AND any other instruction with an a-register operand (on gfx950 the compiler may address them
     directly: `ds_read_b128 a[0:3], ...`, `global_load_dwordx4 a[..]`, `scratch_store_dword ..., a5`, an MFMA with
@@ -73,7 +73,10 @@ def agpr_violations(asm_text: str) -> List[str]:
             code = t.split(";", 1)[0]
             parts = code.split(None, 1)
             if parts[0].startswith("v_accvgpr") or (len(parts) > 1 and _AGPR_OPERAND.search(parts[1])):
-                bad.append(code.strip())
+                # `owned`: the hand-allocated range of the file — hipcc parking a value of its own in an accumulation register
+                # OUTSIDE it (a spill slot under a two-waves-per-SIMD budget) is its business
+                if owned is None or any(k in owned for kind, k in _regs(parts[1] if len(parts) > 1 else "") if kind == "a"):
+                    bad.append(code.strip())
         elif not in_asm and t.startswith(".vgpr_spill_count:"):
             if int(t.split(":", 1)[1]) != 0:
                 bad.append(t + "   (a spilled VGPR next to hand-allocated accumulators)")
@@ -154,7 +157,10 @@ def _check_no_compiler_agprs(hipcc: str, src: str, flags: List[str]) -> None:
         hz = mfma_operand_hazards(r.stdout)
         if hz:
             raise RuntimeError(f"{os.path.basename(src)}: {len(hz)} MFMA operand hazard(s) in the generated code, first: {hz[0]}")
-    bad = agpr_violations(r.stdout)
+    owned = None
+    if os.path.basename(src) == "attention_w.hip":          # O^T: a[0:79] with one wave per SIMD (the default), a[0:39] with two
+        owned = range(0, 40) if "-DVR_ATTN_W_WAVES=8" in flags else range(0, 80)
+    bad = agpr_violations(r.stdout, owned)
     if bad:
         raise RuntimeError(f"{os.path.basename(src)}: hipcc generated `{bad[0]}` (+{len(bad) - 1} more) outside the hand-written "
                            "asm — the accumulation registers are not the compiler's to use in this file (lower the VGPR "
