@@ -230,7 +230,11 @@ def test_attention_vit_running_maximum_is_raised_correctly(case):
     d = qkv.to(DEV)
     out = op_attention(d[:, :hd], d[:, hd:2 * hd], d[:, 2 * hd:], cu.to(DEV), cu.to(DEV), 1, hd, L, False, False,
                        hd ** -0.5, L).float().cpu()
-    ref = _ref_attn(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], False, hd ** -0.5)
+    # Called on its own the kernel multiplies q by scale * log2(e) and rounds the product to bf16 (inside the model that
+    # factor rides the qkv GEMM's epilogue, GemmArgs::col_scale: one rounding).  With keys twelve times the usual size the
+    # second rounding moves a logit by up to 0.05 — the reference models it, so that the test stays about the rescaling.
+    qs = _bf(qkv[:, :hd].float() * (hd ** -0.5 * 1.4426950408889634)).float()
+    ref = torch.softmax(qs @ qkv[:, hd:2 * hd].float().T * 0.6931471805599453, -1) @ qkv[:, 2 * hd:].float()
     assert torch.isfinite(out).all()
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
 

@@ -83,7 +83,10 @@ hipError_t launch_attention72w(const AttnArgs& a, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (a_in.B <= 0 || a_in.max_q <= 0) return hipSuccess;
     if ((a_in.ldq | a_in.ldk | a_in.ldv) % 8 || a_in.ldo % 4) return hipErrorInvalidValue;
-    const AttnArgs& a = a_in;
+    AttnArgs a = a_in;
+    // q rows that already carry scale * log2(e): attention_w.hip takes them as they are, the other kernels multiply the scores by
+    // scale * log2(e) themselves — hand them the scale that makes that factor 1
+    if (a.q_prescaled && !(VR_ATTN_W && attention72w_ok(a))) a.scale = 1.0f / 1.44269504088896340736f;
     // self-attention of short packed sequences (the decoder over a page's 68 tokens): a wave per (sequence, head)
     if (VR_ATTN_SMALL && attention_small_ok(a)) return launch_attention_small(a, s);
     if (VR_ATTN_W && attention72w_ok(a)) return launch_attention72w(a, s);

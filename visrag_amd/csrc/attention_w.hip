@@ -282,6 +282,14 @@ __device__ __forceinline__ void attention72w_body(const AttnArgs& p) {
     bf16x8 qf[NF][2];
     s16x4 qtail[NF];
     auto q_scale = [&]() {
+        if (p.q_prescaled) {              // (wave-uniform) the qkv GEMM's epilogue has multiplied them before ITS rounding
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                qf[f][0] = __builtin_bit_cast(bf16x8, qraw[f][0]); qf[f][1] = __builtin_bit_cast(bf16x8, qraw[f][1]);
+                qtail[f] = __builtin_bit_cast(s16x4, qtraw[f]);
+            }
+            return;
+        }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
 #pragma unroll

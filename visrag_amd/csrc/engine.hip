@@ -728,6 +728,9 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     }
     if (first_group) VRCHK(tap_store(m, "vit_embed", h, N, D, Dp, false, s));
     const int ldqkv = pad128(3 * D);
+    // (the plain bf16 epilogue scales whole 64-column blocks: the q section must end on one, as 16 x 72 does)
+    const int vit_qscale_n = (D % 64 == 0 && !m->ln_fold) ? D : 0;
+    const float vit_qscale = (1.0f / sqrtf(72.0f)) * 1.44269504088896340736f;
     // ln_fold: the residual GEMMs (proj, fc2) leave the bf16 rows of the stream in w_xn and per-row partial sums; the GEMM behind
     // a LayerNorm runs on those rows with pre-scaled weights and applies (rstd, -mean rstd) per row in its epilogue
     const bool fold = m->ln_fold != 0 && (size_t)pad256l(M) * (size_t)std::max(m->Fp, ldqkv) * 2 < (1ull << 31);   // (gemm256w_fits: 32-bit LDS-DMA offsets)
@@ -751,7 +754,13 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
             GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv);
             fold_use(a, b.qkv_c1, b.qkv_c2);
             HIPCHK(launch_gemm256w_ln(a, EPI_BF16, s));
-        } else { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv); HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s)); }
+        } else {
+            // the q columns leave with head_dim^-0.5 * log2(e) folded in before their one bf16 rounding (attention_w.hip starts its
+            // score accumulators at -m and feeds them to v_exp_f32 as they come out)
+            GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv);
+            a.col_scale = vit_qscale; a.col_scale_n = vit_qscale_n;
+            HIPCHK(launch_gemm(a, EPI_BF16, GEMM_VARIANT_AUTO, s));
+        }
         VRCHK(prof_end(m, VR_PROF_VIT_QKV, 2.0 * M * D * 3 * D, s));
         {
             AttnArgs a{};
@@ -759,7 +768,7 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
             a.k = (const char*)m->w_qkv.p + (size_t)D * 2; a.ldk = ldqkv;
             a.v = (const char*)m->w_qkv.p + (size_t)2 * D * 2; a.ldv = ldqkv;
             a.out = m->w_att.p; a.ldo = Dp; a.cu_q = cu_tok; a.cu_kv = cu_tok; a.B = n; a.heads = c.vit_heads;
-            a.head_dim = 72; a.max_q = N; a.causal = 0; a.q_shared = 0; a.scale = 1.0f / sqrtf(72.0f);
+            a.head_dim = 72; a.max_q = N; a.causal = 0; a.q_shared = 0; a.scale = 1.0f / sqrtf(72.0f); a.q_prescaled = vit_qscale_n > 0;
             VRCHK(prof_begin(m, VR_PROF_VIT_ATTN, s));
             HIPCHK(launch_attention(a, s));
             VRCHK(prof_end(m, VR_PROF_VIT_ATTN, 4.0 * n * (double)N * N * D, s));

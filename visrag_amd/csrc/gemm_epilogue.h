@@ -119,6 +119,7 @@ __device__ __forceinline__ void gemm_epilogue_row(f32x4 (&acc)[NF], const GemmAr
             if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
             if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
                 if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
+                if constexpr (EPI == EPI_BF16) { if (nb < p.col_scale_n) v *= p.col_scale; }       // (GemmArgs::col_scale)
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
@@ -247,6 +248,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_general(f32x4 (&acc)[MI][
                     if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
                 }
                 if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
+                if constexpr (EPI == EPI_BF16) { if (nb < p.col_scale_n) v *= p.col_scale; }       // (GemmArgs::col_scale)
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
@@ -352,6 +354,16 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4]
                             acc[c + ii][j] = x1 * cs[ii][j] - x2 * sn[ii][j];
                             acc[c + ii][j + 2] = x2 * cs[ii][j] + x1 * sn[ii][j];
                         }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_BF16) {
+            if (nb < p.col_scale_n) {                  // (wave-uniform: this 64-column block is scaled — the ViT's q heads)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bias[j] *= p.col_scale;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] *= p.col_scale;
                 }
             }
         }

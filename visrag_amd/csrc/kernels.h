@@ -30,6 +30,9 @@ struct GemmArgs {
     int raster_gm;                   // 256-tile kernels: m-tiles per raster group (0 = choose by W size)
     int ksplit;                      // 256-tile kernels, EPI_F32 only: split K over ksplit workgroups per tile;
     size_t split_stride;             //   split s writes its partial product to out + s * split_stride (elements)
+    float col_scale; int col_scale_n;   // optional, bf16-output plain epilogue (EPI_BF16, no row map / row bias): columns n < col_scale_n
+                                     // (a multiple of 64) leave as bf16((acc + bias) * col_scale) — the ViT's q columns carry
+                                     // head_dim^-0.5 * log2(e) into the attention kernel with ONE rounding (attention_w.hip)
     const int* m_dev; int m_sub;     // optional, GEMM_VARIANT_256IL only: rows < *m_dev - m_sub exist (a row count known on the
                                      // device only: tiles at or past it leave at once — the search's band pass)
     // ---- LayerNorm folded into the GEMMs around it (launch_gemm256w_ln only; ln_fold.hip) ----
@@ -105,6 +108,7 @@ struct AttnArgs {
     const int* q_in_rows;            // optional [B]: first q row of item b (overrides cu_q / q_shared for READING q; out rows stay cu_q)
     int q_head_stride;               // elements between the heads of a q row (0: head_dim) — lets the query HEADS of a
                                      // grouped-query group be handed in as the ROWS of one tile (decode: K/V read once per group)
+    int q_prescaled;                 // the q rows already carry scale * log2(e) (GemmArgs::col_scale): the kernels apply no scale
     float* lse;                      // optional f32 [rows_q][heads]: log2 of the row's softmax denominator (with the running
                                      // max folded in) — lets a caller merge attention over separately processed KV ranges
 };
