@@ -265,29 +265,6 @@ int vr_op_gemm(int device_id, const void* A, int32_t lda, const void* W, int32_t
                const float* resid, float alpha, void* out, int32_t ldo,
                const int32_t* rope_pos, const float* rope_table, int32_t rope_cols,
                int32_t variant, void* stream);
-/* EXPERIMENTAL (off unless VR_VIT_LN_FOLD=1 or 2 is in the environment at vr_model_create; written in round 4 without a
- * GPU at hand, to be measured and validated in round 5): the LayerNorms of the ViT blocks folded into the GEMMs around
- * them,  LN(x) W^T + bias = rstd ((x o gamma) W^T) - rstd mean c1 + c2  with  c1[n] = sum_k gamma[k] W[n][k],
- * c2 = bias + W beta.  The pieces, for tests:
- *   vr_op_ln_fold_weights: W bf16 [n_pad][ldw] (k real columns), gamma / beta f32 [k], bias f32 [n_pad] or NULL
- *                          -> c1 / c2 f32 [n_pad];
- *   vr_op_gemm_ln, epilogue 3 (residual, N % 192 == 0): out = resid + acc + bias in fp32 (in place when out == resid)
- *                          AND ln_x = bf16(out o ln_gamma) [M][ln_ldx] (ln_gamma f32 [N]: the FOLLOWING LayerNorm's weight),
- *                          ln_part f32 [M][ln_parts = 2 N / 192][2] = per row and 96-column range the (sum, sum of
- *                          squares) of out;
- *   vr_op_ln_fold_stats:   ln_part -> ab f32 [rows][2] = (rstd, -mean rstd), biased variance over dim columns;
- *   vr_op_gemm_ln, epilogue 0 / 1: out bf16 = [gelu](ab[m][0] acc + ab[m][1] ln_c1[n] + bias[n]); with ln_ab == NULL the
- *                          kernel computes ab itself from ln_part / ln_parts over ln_dim columns with ln_eps (fp32; what
- *                          VR_VIT_LN_FOLD=2 runs: no statistics launch).
- * Buffers padded to a multiple of 256 rows. */
-int vr_op_gemm_ln(int device_id, const void* A, int32_t lda, const void* W, int32_t ldw, int32_t M, int32_t N, int32_t K,
-                  int32_t epilogue, const float* bias, const float* resid, void* out, int32_t ldo, void* ln_x,
-                  int32_t ln_ldx, const float* ln_gamma, float* ln_part, int32_t ln_parts, const float* ln_ab,
-                  const float* ln_c1, int32_t ln_dim, float ln_eps, void* stream);
-int vr_op_ln_fold_stats(int device_id, const float* part, int32_t parts, int32_t rows, int32_t dim, float eps, float* ab,
-                        void* stream);
-int vr_op_ln_fold_weights(int device_id, const void* W, int32_t n_pad, int32_t k, int32_t ldw, const float* gamma,
-                          const float* beta, const float* bias, float* c1, float* c2, void* stream);
 /* y = LN(x) (kind 0, affine, eps) or RMSNorm(x) (kind 1): x f32 [rows][dim] -> bf16 [rows][ldo]. */
 int vr_op_norm(int device_id, int32_t kind, const float* x, int32_t rows, int32_t dim,
                const float* weight, const float* bias, float eps, void* out, int32_t ldo,

@@ -89,10 +89,6 @@ SIGNATURES = {
     "vr_op_gemm": (C.c_int, [C.c_int, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32,
                              _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "vr_op_norm": (C.c_int, [C.c_int, _i32, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp]),
-    "vr_op_gemm_ln": (C.c_int, [C.c_int, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32,
-                                _vp, _vp, _i32, _f32, _vp]),
-    "vr_op_ln_fold_stats": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _f32, _vp, _vp]),
-    "vr_op_ln_fold_weights": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vr_op_attention": (C.c_int, [C.c_int, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32,
                                   _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
 }

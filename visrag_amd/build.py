@@ -18,7 +18,7 @@ from typing import Iterable, List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "ln_fold.hip", "gemm_skinny.hip", "gen_persist.hip", "norm.hip", "attention.hip", "attention_w.hip", "attention_small.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip", "search256w.hip",
+SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "gemm_skinny.hip", "gen_persist.hip", "norm.hip", "attention.hip", "attention_w.hip", "attention_small.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip", "search256w.hip",
            "search_small.hip", "search_bigk.hip", "search_exact.hip", "search_band.hip", "hp_text.hip", "resize.hip", "synth.hip", "pack.hip", "engine.hip", "gen_kernels.hip", "gen.hip", "gen_vision.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: relaxed NaN handling only (infinities are honoured: masked scores are -inf).  Without it

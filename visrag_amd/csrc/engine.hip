@@ -30,8 +30,6 @@ extern "C" int vr_device_count(int* count) {
 
 struct VitBlock {
     Vec n1w, n1b, n2w, n2b; Linear qkv, proj, fc1, fc2;
-    // LayerNorm folded into the GEMM behind it (ln_fold; kernels.h: launch_gemm256w_ln): c1 = W gamma, c2 = bias + W beta
-    Vec qkv_c1, qkv_c2, fc1_c1, fc1_c2;
 };
 struct DecLayer {
     Vec ln1, ln2; Linear qkv, o, gu, down; int parts_qkv = 0, parts_gu = 0;
@@ -52,7 +50,6 @@ struct vr_model_s {
     bool finalized = false, taps_on = false;
     int pool_mode = 0;                        // VR_POOL_*
     bool borrowed = false;                    // vr_model_clone: weights belong to another handle
-    int ln_fold = 0;                          // VR_VIT_LN_FOLD=1 / 2 at vr_model_create: the ViT blocks' LayerNorms folded into the GEMMs around them
     // dims
     int D = 0, Dp = 0, F = 0, Fp = 0, E = 0, I = 0, Ip = 0, Kpe = 0, Kpe_p = 0, Q = 0;
     // weights
@@ -79,7 +76,6 @@ struct vr_model_s {
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
     DevBuf w_hp_hi, w_hp_planes, w_hp_qkv, w_hp_att, w_hp_gu, w_seqof;   // split-precision text path (hp_text.hip)
     DevBuf w_hp_part;                                                 // its split-K planes for short batches (grown on demand)
-    DevBuf w_lnpart, w_lnab;                  // ln_fold: per-row partial sums [M][2 N / 192][2] and (rstd, -mean rstd) [M][2], f32
     std::map<std::string, Tap> taps;
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
     // stream, elapsed times summed lazily in vr_model_get_profile
@@ -167,10 +163,6 @@ extern "C" int vr_model_create(int device_id, const vr_config_t* cfg, vr_model_t
     m->Q = c.query_num;
     m->blocks.resize(c.vit_depth);
     m->layers.resize(c.num_layers);
-    // experimental (built in round 4 without a GPU at hand, to be measured): the ViT blocks' LayerNorms folded into the
-    // GEMMs around them.  Needs the 256 x 192 residual tile (vit_dim % 192 == 0, no padding columns).
-    const char* lf = getenv("VR_VIT_LN_FOLD");          // 1: a statistics launch between producer and consumer; 2: the consumer computes them itself
-    m->ln_fold = (lf && lf[0] >= '1' && lf[0] <= '2' && c.vit_dim % 192 == 0 && m->Dp == c.vit_dim && c.vit_dim / 192 <= 8) ? lf[0] - '0' : 0;
     *out = m;
     return VR_OK;
 }
@@ -184,7 +176,6 @@ extern "C" int vr_model_destroy(vr_model_t m) {
         fl(m->patch); fl(m->r_kvproj); fl(m->r_kv); fl(m->r_out); fl(m->r_proj);
         for (auto& b : m->blocks) {
             fl(b.qkv); fl(b.proj); fl(b.fc1); fl(b.fc2); b.n1w.v.free(); b.n1b.v.free(); b.n2w.v.free(); b.n2b.v.free();
-            b.qkv_c1.v.free(); b.qkv_c2.v.free(); b.fc1_c1.v.free(); b.fc1_c2.v.free();
         }
         for (auto& l : m->layers) { fl(l.qkv); fl(l.o); fl(l.gu); fl(l.down); fl(l.qkv_lo); fl(l.o_lo); fl(l.gu_lo); fl(l.down_lo); l.ln1.v.free(); l.ln2.v.free(); }
         for (Vec* v : {&m->vit_nw, &m->vit_nb, &m->r_lnq_w, &m->r_lnq_b, &m->r_lnkv_w, &m->r_lnkv_b, &m->r_lnpost_w, &m->r_lnpost_b, &m->final_norm}) v->v.free();
@@ -472,10 +463,6 @@ static int alloc_workspace(vr_model_s* m) {
     VRCHK(m->w_rowmap.alloc((size_t)R * 4));
     VRCHK(m->w_imgptr.alloc((size_t)c.max_images * 8));
     VRCHK(m->w_out.alloc((size_t)c.max_seqs * E * 4));
-    if (m->ln_fold) {
-        VRCHK(m->w_lnpart.alloc((size_t)M * (2 * (m->D / 192)) * 2 * 4 + 256));      // (+ a row's worth of slack behind the last row)
-        VRCHK(m->w_lnab.alloc((size_t)M * 2 * 4));
-    }
     if (c.text_split_precision) {
         const int Kmax = std::max(E, m->Ip);
         VRCHK(m->w_hp_hi.alloc((size_t)2 * T * Kmax * 2));       // [hi rows | lo rows]: the lo half starts right behind the batch's T hi rows
@@ -583,24 +570,6 @@ extern "C" int vr_model_finalize(vr_model_t m) {
             HIPCHK(hipMemcpy(&any, flag.p, 4, hipMemcpyDeviceToHost));
             if (!any) { m->embed_lo.free(); m->has_embed_lo = false; }
         }
-    }
-    if (m->ln_fold) {
-        // c1 = W gamma, c2 = bias + W beta: block l's norm2 -> fc1, and norm1 -> qkv for l >= 1
-        // (block 0's norm1 follows the patch embedding, which is not a residual GEMM: it stays a LayerNorm launch)
-        auto fold = [&](const Linear& L, const Vec& g, const Vec& b, Vec& c1, Vec& c2) -> int {
-            VRCHK(c1.v.alloc((size_t)L.n_pad * 4));
-            VRCHK(c2.v.alloc((size_t)L.n_pad * 4));
-            c1.ok = c2.ok = true;
-            HIPCHK(launch_ln_fold_weights(L.w.p, L.n_pad, L.k, L.k_pad, g.v.as<float>(), b.v.as<float>(), L.has_b ? L.b.as<float>() : nullptr,
-                                          c1.v.as<float>(), c2.v.as<float>(), 0));
-            return VR_OK;
-        };
-        for (int n = 0; n < c.vit_depth; ++n) {
-            VitBlock& b = m->blocks[n];
-            if (n > 0) VRCHK(fold(b.qkv, b.n1w, b.n1b, b.qkv_c1, b.qkv_c2));
-            VRCHK(fold(b.fc1, b.n2w, b.n2b, b.fc1_c1, b.fc1_c2));
-        }
-        HIPCHK(hipDeviceSynchronize());
     }
     if (!m->w_h.p) VRCHK(alloc_workspace(m));
     m->finalized = true;
@@ -729,32 +698,13 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     if (first_group) VRCHK(tap_store(m, "vit_embed", h, N, D, Dp, false, s));
     const int ldqkv = pad128(3 * D);
     // (the plain bf16 epilogue scales whole 64-column blocks: the q section must end on one, as 16 x 72 does)
-    const int vit_qscale_n = (D % 64 == 0 && !m->ln_fold) ? D : 0;
+    const int vit_qscale_n = D % 64 == 0 ? D : 0;
     const float vit_qscale = (1.0f / sqrtf(72.0f)) * 1.44269504088896340736f;
-    // ln_fold: the residual GEMMs (proj, fc2) leave the bf16 rows of the stream in w_xn and per-row partial sums; the GEMM behind
-    // a LayerNorm runs on those rows with pre-scaled weights and applies (rstd, -mean rstd) per row in its epilogue
-    const bool fold = m->ln_fold != 0 && (size_t)pad256l(M) * (size_t)std::max(m->Fp, ldqkv) * 2 < (1ull << 31);   // (gemm256w_fits: 32-bit LDS-DMA offsets)
-    const int ln_parts = 2 * (D / 192);
-    auto fold_emit = [&](GemmArgs& a, const Vec& gamma) {       // gamma: the weight of the LayerNorm that follows
-        a.ln_x = m->w_xn.p; a.ln_ldx = Dp; a.ln_gamma = gamma.v.as<float>(); a.ln_part = m->w_lnpart.as<float>(); a.ln_parts = ln_parts;
-    };
-    const bool fold_stats = m->ln_fold == 1;      // a statistics launch; else the consuming GEMM's workgroups compute their rows' themselves
-    auto fold_use = [&](GemmArgs& a, const Vec& c1, const Vec& c2) {
-        a.ln_c1 = c1.v.as<float>(); a.bias = c2.v.as<float>();
-        if (fold_stats) a.ln_ab = m->w_lnab.as<float>();
-        else { a.ln_part = m->w_lnpart.as<float>(); a.ln_parts = ln_parts; a.ln_dim = D; a.ln_eps = c.vit_ln_eps; }
-    };
     for (int l = 0; l < c.vit_depth; ++l) {
         const VitBlock& b = m->blocks[l];
-        const bool fold_qkv = fold && l > 0;
-        if (!fold_qkv) HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
-        else if (fold_stats) HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
+        HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_QKV, s));
-        if (fold_qkv) {
-            GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv);
-            fold_use(a, b.qkv_c1, b.qkv_c2);
-            HIPCHK(launch_gemm256w_ln(a, EPI_BF16, s));
-        } else {
+        {
             // the q columns leave with head_dim^-0.5 * log2(e) folded in before their one bf16 rounding (attention_w.hip starts its
             // score accumulators at -m and feeds them to v_exp_f32 as they come out)
             GemmArgs a = gemm_args(m->w_xn.p, Dp, b.qkv, M, m->w_qkv.p, ldqkv);
@@ -776,24 +726,17 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
         VRCHK(prof_begin(m, VR_PROF_VIT_PROJ, s));
         {
             GemmArgs a = gemm_args(m->w_att.p, Dp, b.proj, M, h, Dp); a.resid = h;
-            if (fold) { fold_emit(a, b.n2w); HIPCHK(launch_gemm256w_ln(a, EPI_RESID, s)); }
-            else HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
+            HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
         }
         VRCHK(prof_end(m, VR_PROF_VIT_PROJ, 2.0 * M * D * D, s));
-        if (!fold) HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
-        else if (fold_stats) HIPCHK(launch_ln_fold_stats(m->w_lnpart.as<float>(), ln_parts, M, D, c.vit_ln_eps, m->w_lnab.as<float>(), s));
+        HIPCHK(launch_layernorm(h, M, D, Dp, b.n2w.v.as<float>(), b.n2b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC1, s));
-        if (fold) {
-            GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp);
-            fold_use(a, b.fc1_c1, b.fc1_c2);
-            HIPCHK(launch_gemm256w_ln(a, EPI_GELU, s));
-        } else { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_AUTO, s)); }
+        { GemmArgs a = gemm_args(m->w_xn.p, Dp, b.fc1, M, m->w_mlp.p, m->Fp); HIPCHK(launch_gemm(a, EPI_GELU, GEMM_VARIANT_AUTO, s)); }
         VRCHK(prof_end(m, VR_PROF_VIT_FC1, 2.0 * M * D * m->F, s));
         VRCHK(prof_begin(m, VR_PROF_VIT_FC2, s));
         {
             GemmArgs a = gemm_args(m->w_mlp.p, m->Fp, b.fc2, M, h, Dp); a.resid = h;
-            if (fold && l + 1 < c.vit_depth) { fold_emit(a, m->blocks[l + 1].n1w); HIPCHK(launch_gemm256w_ln(a, EPI_RESID, s)); }   // (the last block is followed by the post-LayerNorm launch)
-            else HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
+            HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
         }
         VRCHK(prof_end(m, VR_PROF_VIT_FC2, 2.0 * M * D * m->F, s));
         if (l == 0 && first_group) VRCHK(tap_store(m, "vit_block0", h, N, D, Dp, false, s));
@@ -1217,8 +1160,7 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
                       &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out,
-                      &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part,
-                      &m->w_lnpart, &m->w_lnab}) {
+                      &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part}) {
         b->free();                                 // (a non-owning alias after the copy: just forget it)
     }
     m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)
@@ -1626,35 +1568,6 @@ extern "C" int vr_synth_pages(int device_id, uint8_t* out, int32_t n, int32_t si
     if (!out || n < 0 || size < 64 || size > 4096) return fail(VR_ERR_INVALID, "bad synth_pages arguments");
     VRCHK(set_dev(device_id));
     HIPCHK(launch_synth_pages(out, n, size, seed, first, (hipStream_t)stream));
-    return VR_OK;
-}
-
-// ------------------------------------------------ LayerNorm folded into GEMMs: op level ---
-extern "C" int vr_op_gemm_ln(int device_id, const void* A, int32_t lda, const void* W, int32_t ldw, int32_t M, int32_t N, int32_t K,
-                             int32_t epilogue, const float* bias, const float* resid, void* out, int32_t ldo, void* ln_x,
-                             int32_t ln_ldx, const float* ln_gamma, float* ln_part, int32_t ln_parts, const float* ln_ab, const float* ln_c1,
-                             int32_t ln_dim, float ln_eps, void* stream) {
-    if (!A || !W || !out) return fail(VR_ERR_INVALID, "NULL argument");
-    if (M <= 0 || K % 64 || N % 128) return fail(VR_ERR_INVALID, "need M > 0, N %% 128 == 0, K %% 64 == 0");
-    VRCHK(set_dev(device_id));
-    GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid; a.alpha = 1.0f;
-    a.out = out; a.ldo = ldo; a.ln_x = ln_x; a.ln_ldx = ln_ldx; a.ln_gamma = ln_gamma; a.ln_part = ln_part; a.ln_parts = ln_parts; a.ln_ab = ln_ab; a.ln_c1 = ln_c1; a.ln_dim = ln_dim; a.ln_eps = ln_eps;
-    HIPCHK(launch_gemm256w_ln(a, epilogue, (hipStream_t)stream));
-    return VR_OK;
-}
-
-extern "C" int vr_op_ln_fold_stats(int device_id, const float* part, int32_t parts, int32_t rows, int32_t dim, float eps, float* ab,
-                                   void* stream) {
-    VRCHK(set_dev(device_id));
-    HIPCHK(launch_ln_fold_stats(part, parts, rows, dim, eps, ab, (hipStream_t)stream));
-    return VR_OK;
-}
-
-extern "C" int vr_op_ln_fold_weights(int device_id, const void* W, int32_t n_pad, int32_t k, int32_t ldw, const float* gamma,
-                                     const float* beta, const float* bias, float* c1, float* c2, void* stream) {
-    VRCHK(set_dev(device_id));
-    HIPCHK(launch_ln_fold_weights(W, n_pad, k, ldw, gamma, beta, bias, c1, c2, (hipStream_t)stream));
     return VR_OK;
 }
 

@@ -65,42 +65,11 @@ constexpr unsigned W_OOB = 0x80000000u;            // per-lane offset beyond the
 constexpr int W_STAGING = 4096;                            // epilogue staging per wave: one piece of 32 rows x 64 bf16
 constexpr int W_SMEM_BYTES = 2 * W_STAGE + 4 * W_STAGING;  // two stages + staging = 144 KiB
 
-constexpr int W_LN_AB = 1024;                              // LNF = 2: a wave's 128 rows x (a, b), fetched by LDS-DMA at tile start
-constexpr int W_SMEM_BYTES_LN = W_SMEM_BYTES + 4 * W_LN_AB;
-
-// LNF (LayerNorm folded into the GEMMs around it, kernels.h: launch_gemm256w_ln; 0 in every kernel of the default path):
-//   1  EPI_RESID producer: next to the fp32 result x its rows as bf16(x o gamma) (ln_x) and, per row and wave column range, the partial
-//      (sum, sum of squares) of the stored values (ln_part);
-//   2  EPI_BF16 / EPI_GELU consumer: acc <- a[row] * acc + b[row] * c1[col] before the usual epilogue (bias = c2);
-//   3  the same, (a, b) = (rstd, -mean rstd) computed here from the producer's partial sums (fp32), no statistics launch.
 #define W_KERNEL_TEMPLATE template <int EPI, bool PLAIN, int NJ>
 #define W_KERNEL_NAME gemm256w_bf16_kernel
-#define W_KERNEL_LNF 0
 #include "gemm256w_kernel.h"
 #undef W_KERNEL_TEMPLATE
 #undef W_KERNEL_NAME
-#undef W_KERNEL_LNF
-#define W_KERNEL_TEMPLATE template <int EPI, bool PLAIN, int NJ, int LNF_>
-#define W_KERNEL_NAME gemm256w_ln_kernel
-#define W_KERNEL_LNF LNF_
-#include "gemm256w_kernel.h"
-#undef W_KERNEL_TEMPLATE
-#undef W_KERNEL_NAME
-#undef W_KERNEL_LNF
-
-template <int EPI, bool PLAIN, int NJ, int LNF>
-static hipError_t launch_wp_ln(GemmArgs a, hipStream_t s) {
-    constexpr int BN = 32 * NJ;
-    const int tn = (a.N + BN - 1) / BN, tm = (a.M + G256_BM - 1) / G256_BM;
-    if (a.raster_gm <= 0) a.raster_gm = tm <= 16 ? tm : 4;
-    if (!gemm256w_fits(a, BN) || a.ksplit > 1) return hipErrorInvalidValue;
-    auto k = gemm256w_ln_kernel<EPI, PLAIN, NJ, LNF>;
-    constexpr int smem = LNF >= 2 ? W_SMEM_BYTES_LN : W_SMEM_BYTES;
-    static unsigned long long attr = 0;     // bit d: set on device d
-    set_max_dynamic_lds((const void*)k, smem, attr);
-    hipLaunchKernelGGL(k, dim3(tn * tm), dim3(256), smem, s, a);
-    return hipGetLastError();
-}
 
 template <int EPI, bool PLAIN, int NJ>
 static hipError_t launch_wp(GemmArgs a, hipStream_t s) {
@@ -144,23 +113,6 @@ hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_ROPE: return launch_w<EPI_ROPE>(a, s);
         default: return hipErrorInvalidValue;
     }
-}
-
-// LayerNorm folded into the GEMMs around it (kernels.h)
-hipError_t launch_gemm256w_ln(const GemmArgs& a, int epi, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
-    if (a.rowmap || a.rowbias) return hipErrorInvalidValue;
-    if (epi == EPI_RESID) {
-        if (!a.ln_x || !a.ln_part || !a.ln_gamma || a.N % 192 || a.ln_parts != (a.N / 192) * 2 || !a.resid || (a.ln_ldx & 3)) return hipErrorInvalidValue;
-        return launch_wp_ln<EPI_RESID, false, 6, 1>(a, s);
-    }
-    if (epi == EPI_BF16 || epi == EPI_GELU) {
-        if (!a.ln_c1 || (a.N & 7) || (a.ldo & 7)) return hipErrorInvalidValue;
-        if (a.ln_ab) return epi == EPI_BF16 ? launch_wp_ln<EPI_BF16, true, 8, 2>(a, s) : launch_wp_ln<EPI_GELU, true, 8, 2>(a, s);
-        if (!a.ln_part || a.ln_parts <= 0 || a.ln_parts > 16 || a.ln_dim <= 0) return hipErrorInvalidValue;
-        return epi == EPI_BF16 ? launch_wp_ln<EPI_BF16, true, 8, 3>(a, s) : launch_wp_ln<EPI_GELU, true, 8, 3>(a, s);
-    }
-    return hipErrorInvalidValue;
 }
 
 // 256 x 192 tile: N % 192 == 0, residual (the SigLIP proj / fc2 GEMMs) and fp32 (split-K partial products of the

@@ -1,11 +1,7 @@
-// The kernel text of gemm256w.hip, included once per kernel NAME (see there): the default kernels keep their three
-// template parameters — and with them the names the profiles, traffic tables and bench.py know them by — while the forms
-// with a LayerNorm folded in are separate kernels.  W_KERNEL_TEMPLATE / W_KERNEL_NAME / W_KERNEL_LNF are set by the includer.
+// The kernel text of gemm256w.hip (W_KERNEL_TEMPLATE / W_KERNEL_NAME are set by the includer).
 W_KERNEL_TEMPLATE
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void W_KERNEL_NAME(GemmArgs p) {
-    constexpr int LNF = W_KERNEL_LNF;
     static_assert(NJ == 8 || (NJ == 6 && !PLAIN), "wave tile 128 x 128 or 128 x 96");
-    static_assert(LNF == 0 || (LNF == 1 && EPI == EPI_RESID) || ((LNF == 2 || LNF == 3) && PLAIN && (EPI == EPI_BF16 || EPI == EPI_GELU)), "LNF forms");
     constexpr int BN = 32 * NJ;                 // tile columns
     constexpr int NS = 8 * NJ;                  // MFMAs per phase (slots)
     constexpr int NR = 8 + NJ;                  // fragment reads per k-half = LDS-DMA loads per K-step and wave
@@ -101,28 +97,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #endif
 
-    if constexpr (LNF == 2) {
-        // this wave's 128 rows of (a, b): 256 dwords by LDS-DMA, no registers; the wave's OLDEST loads, so every vmcnt wait of
-        // the K-loop covers them and the epilogue finds them in LDS
-        char* const abl = smem + W_SMEM_BYTES + wave * W_LN_AB;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int d = it * 64 + lane;
-            const float* src = p.ln_ab + (size_t)min(m0 + wm * 128 + (d >> 1), p.M - 1) * 2 + (d & 1);
-            __builtin_amdgcn_global_load_lds(VR_GLOBAL(src), VR_LDS(abl + it * 256), 4, 0, 0);
-        }
-    }
-
-    // LNF = 3: thread t asks for the partial sums of row m0 + t now (its oldest loads) and turns them into (a, b) under the
-    // latency of the prologue's operand loads; the prologue's barrier publishes the 256 pairs to the four waves
-    constexpr int LN_MAXP = 16;
-    [[maybe_unused]] f32x2 ln_pv[LNF == 3 ? LN_MAXP : 1];
-    if constexpr (LNF == 3) {
-        const f32x2* pp = reinterpret_cast<const f32x2*>(p.ln_part) + (size_t)min(m0 + (int)threadIdx.x, p.M - 1) * p.ln_parts;
-#pragma unroll
-        for (int i = 0; i < LN_MAXP; ++i) ln_pv[i] = i < p.ln_parts ? pp[i] : f32x2{0.f, 0.f};
-    }
-
     // ---- prologue: K-steps 0 and 1 in flight, the accumulators zeroed under their latency (256 register writes:
     //      half a microsecond), k-half-0 fragments of step 0 requested
     {
@@ -132,18 +106,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int d = 0; d < NR; ++d) dma(1, d, lofA + curA + k1, lofW + curW + k1);
         W_FOR_EACH_ACC(W_ZERO)
-        if constexpr (LNF == 3) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_MAXP; ++i) { s1 += ln_pv[i][0]; s2 += ln_pv[i][1]; }       // (index order: fixed)
-            const float inv = 1.0f / (float)p.ln_dim;
-            const float mean = s1 * inv;
-            const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.f);
-            const float rstd = 1.0f / __builtin_sqrtf(var + p.ln_eps);
-            typedef __attribute__((address_space(3))) f32x2* ab_w;
-            ((ab_w)VR_LDS(smem + W_SMEM_BYTES))[threadIdx.x] = f32x2{rstd, -mean * rstd};
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               // (written before the barrier below)
-        }
         if constexpr (NJ == 8) VR_WAIT_VM_BARRIER(16); else VR_WAIT_VM_BARRIER(14);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) w0[j] = pW[0][0][j * 128];
@@ -260,19 +222,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     bias[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(nb0 + j * 16 + fq * 4, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                [[maybe_unused]] f32x4 ln_g[LNF == 1 ? NJ : 1];          // LNF = 1: the following LayerNorm's weight for this lane's columns
-                if constexpr (LNF == 1) {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) ln_g[j] = *reinterpret_cast<const f32x4*>(p.ln_gamma + min(nb0 + j * 16 + fq * 4, p.N - 4));
-                }
-                constexpr int LN_PITCH = 112;            // bytes per staged row: 96 of data, 16-byte aligned chunks
-                typedef __attribute__((address_space(3))) char* ln_lds_p;
-                [[maybe_unused]] const ln_lds_p ln_st = (ln_lds_p)VR_LDS(wl0);
-                [[maybe_unused]] float ln_s1[4][MI], ln_s2[4][MI];          // LNF = 1: this lane's share of the row sums (rows (sg, i), its 4-column groups)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) { ln_s1[g][i] = 0.f; ln_s2[g][i] = 0.f; }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int h = q & 1, sg = q >> 1;
@@ -293,72 +242,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             if (m < p.M && n < p.N && vv[0] == 123456.78f)
                                 *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = vv;
 #else
-                            if constexpr (LNF == 1) {
-                                const f32x4 vv = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
-                                // the bf16 row goes through this wave's LDS slice (below): a direct store would be 8 bytes per
-                                // lane, 32-byte segments — measured (round 4, first run): proj 3.31 -> 4.11, fc2 7.84 -> 8.85 ms per step
-                                *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(ln_st + (i * 16 + fr) * LN_PITCH + j * 32 + fq * 8) =
-                                    __builtin_convertvector(vv * ln_g[h * NF + j], bf16x4);
-                                if (m < p.M && n < p.N) {
-                                    *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = vv;
-                                    ln_s1[sg][i] += (vv[0] + vv[1]) + (vv[2] + vv[3]);
-                                    ln_s2[sg][i] += (vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3]);
-                                }
-                            } else {
-                                if (m < p.M && n < p.N)
-                                    *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
-                            }
+                            if (m < p.M && n < p.N)
+                                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
 #endif
-                        }
-                    }
-                    if constexpr (LNF == 1) {
-                        // read the piece back row-wise (a wave's LDS operations execute in order): 32 rows x 96 bytes = 192 chunks of 16 bytes
-                        static_assert(NF == 3, "96-byte row segments");
-                        u32x4 d[3];
-#pragma unroll
-                        for (int it = 0; it < 3; ++it) {
-                            const int idx = it * 64 + lane, row = idx / 6, ch = idx - row * 6;
-                            d[it] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(ln_st + row * LN_PITCH + ch * 16);
-                        }
-#pragma unroll
-                        for (int it = 0; it < 3; ++it) {
-                            const int idx = it * 64 + lane, row = idx / 6, ch = idx - row * 6;
-                            const int m = mrow0 + sg * 32 + row, n = nb0 + h * (16 * NF) + ch * 8;
-                            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>((bf16_t*)p.ln_x + (size_t)m * p.ln_ldx + n) = d[it];
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (LNF == 1) {
-                    // a row's four column quads sit in lanes fr, fr + 16, fr + 32, fr + 48: fold them, lane fr writes the
-                    // partial of (row, tile column, wave column range)
-                    const int pi = (n0 / BN) * 2 + wn;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) {
-                            float a = ln_s1[g][i], b = ln_s2[g][i];
-                            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-                            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-                            const int m = mrow0 + (g * MI + i) * 16 + fr;
-                            if (fq == 0 && m < p.M)
-                                *reinterpret_cast<f32x2*>(p.ln_part + ((size_t)m * p.ln_parts + pi) * 2) = f32x2{a, b};
-                        }
-                }
             }
-        }
-        // LNF = 2 / 3: c1 and c2 of this wave's columns, requested once for the whole tile (a request per piece — 0.5 us of latency
-        // each behind the scheduling barriers — and a separate bias pass cost qkv + 0.36, fc1 + 0.55 ms per step in the first run)
-        [[maybe_unused]] f32x4 ln_c1v[LNF >= 2 ? NJ : 1], ln_c2v[LNF >= 2 ? NJ : 1];
-        [[maybe_unused]] GemmArgs pq = p;
-        if constexpr (LNF >= 2) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = min(nb0 + j * 16 + fq * 4, p.N - 4);
-                ln_c1v[j] = *reinterpret_cast<const f32x4*>(p.ln_c1 + n);
-                ln_c2v[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            pq.bias = nullptr;                          // (added here, with the correction)
         }
         if (!plain_resid) {
 #pragma unroll
@@ -407,20 +298,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     gemm_epilogue_resid_tile<MI, NF, 2>(acc, p, mr + fr, nb, fq);
                     done = true;
                 }
-                if constexpr (LNF == 2 || LNF == 3) {
-                    // acc <- a[row] acc + b[row] c1[col]   (then bias = c2 and the activation, below)
-                    typedef const __attribute__((address_space(3))) f32x2* ab_p;
-                    const ab_p abl = (ab_p)VR_LDS(smem + W_SMEM_BYTES + (LNF == 2 ? wave * W_LN_AB : wm * 128 * 8));
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const f32x2 ab = abl[sg * 32 + i * 16 + fr];
-#pragma unroll
-                        for (int j = 0; j < NF; ++j) acc[i][j] = acc[i][j] * ab[0] + (ln_c1v[h * NF + j] * ab[1] + ln_c2v[h * NF + j]);
-                    }
-                }
                 if constexpr (NF == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE)) {
                     if constexpr (PLAIN) {
-                        gemm_epilogue_tile_lds_plain<EPI, MI>(acc, LNF >= 2 ? pq : p, mr, nb, lane, wl0);
+                        gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mr, nb, lane, wl0);
                         done = true;
                     } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
                         gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl0);

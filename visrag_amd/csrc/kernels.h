@@ -35,13 +35,6 @@ struct GemmArgs {
                                      // head_dim^-0.5 * log2(e) into the attention kernel with ONE rounding (attention_w.hip)
     const int* m_dev; int m_sub;     // optional, GEMM_VARIANT_256IL only: rows < *m_dev - m_sub exist (a row count known on the
                                      // device only: tiles at or past it leave at once — the search's band pass)
-    // ---- LayerNorm folded into the GEMMs around it (launch_gemm256w_ln only; ln_fold.hip) ----
-    void* ln_x; int ln_ldx;          // EPI_RESID producer: bf16(x o gamma) of the updated residual rows x, [M][ln_ldx] ...
-    const float* ln_gamma;           //   (gamma f32 [N]: the weight of the LayerNorm that FOLLOWS this GEMM)
-    float* ln_part; int ln_parts;    //   ... and per (row, 96-column half tile) the partial (sum, sum of squares): f32 [M][ln_parts][2]
-    const float* ln_ab;              // EPI_BF16 / EPI_GELU consumer: per row (a, b) = (rstd, -mean * rstd): f32 [M][2]
-    const float* ln_c1;              //   per column c1[n] = sum_k gamma[k] W[n][k]:  out = epi(a * acc + b * c1 + bias)   (bias = c2)
-    int ln_dim; float ln_eps;        //   ln_ab == null: (a, b) computed by the consumer itself from ln_part / ln_parts (<= 16) over ln_dim columns
 };
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // 256x192 tile (gemm192.hip): N % 192 == 0, epilogues BF16 / GELU / F32 / RESID only
@@ -51,21 +44,6 @@ hipError_t launch_gemm256w(const GemmArgs& a, int epilogue, hipStream_t s);
 bool gemm256w_fits(const GemmArgs& a, int tile_cols);   // its 32-bit LDS-DMA offsets cover both operands
 // its 256x192 form: N % 192 == 0, EPI_RESID and EPI_F32 (incl. ksplit)
 hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
-// LayerNorm folded into the one-wave-per-SIMD GEMMs (off unless the engine is told to: VR_VIT_LN_FOLD=1 / 2).
-//   y = LN(x) W^T + bias = rstd ((x o gamma) W^T) - rstd mean c1 + c2,   c1[n] = sum_k gamma[k] W[n][k],  c2 = bias + W beta
-// so the GEMM that CONSUMES a LayerNorm runs on bf16(x o gamma) with its own weights and corrects per row in its
-// epilogue, and the residual GEMM that PRODUCES x writes those bf16 rows (ONE rounding per value, like the bf16 output of
-// the LayerNorm kernel) and per-row partial sums next to its fp32 result: the LayerNorm kernel between them (226 MB per
-// launch of the ViT: 44 us, 52 per step) is gone.
-//   EPI_RESID (256x192 tile, N % 192 == 0): also writes ln_x and ln_part;
-//   EPI_BF16 / EPI_GELU (256x256 tile, plain outputs): applies ln_ab / ln_c1 — or, with ln_ab == null, computes a tile's 256
-//   (a, b) itself from the partial sums while its first operand loads are in flight (no statistics launch in between).
-hipError_t launch_gemm256w_ln(const GemmArgs& a, int epilogue, hipStream_t s);
-// partial sums -> (rstd, -mean rstd) per row (biased variance over `dim` columns, like nn.LayerNorm)
-hipError_t launch_ln_fold_stats(const float* part, int parts, int rows, int dim, float eps, float* ab, hipStream_t s);
-// W [n_pad][ldw] bf16, gamma / beta f32 [k] -> c1[n] = sum_k gamma[k] W[n][k], c2[n] = bias[n] + sum_k beta[k] W[n][k]
-hipError_t launch_ln_fold_weights(const void* W, int n_pad, int k, int ldw, const float* gamma, const float* beta, const float* bias,
-                                  float* c1, float* c2, hipStream_t s);
 
 // M <= 16 rows (gemm_skinny.hip): the decode step's weight streamer; fp32 planes out[split][M][ldo] (+ bias with split 0)
 // swiglu (ksplit 1, 16-row [gate | up] interleaved W): out = bf16 act [M][ldo] = silu(gate) * up instead of a plane
