@@ -361,6 +361,17 @@ def main():
         barrier()
         gather_us = max_over_ranks(time.perf_counter() - tg0) / 20 * 1e6
 
+    # who took part in the exchange: every rank's id and the rows of ITS shard, all-gathered (the driver's N > 1 lines show which
+    # transport ran and that every GPU held a shard)
+    ranks_seen = rows_per_rank = None
+    if world > 1:
+        me = torch.tensor([rank, srch["rows_per_gpu"], local_rank], dtype=torch.int64, device="cpu" if shared else dev)
+        allr = torch.empty((world, 3), dtype=torch.int64, device=me.device)
+        dist.all_gather_into_tensor(allr, me)
+        allr = allr.cpu().tolist()
+        ranks_seen = sorted(int(r[0]) for r in allr)
+        rows_per_rank = [int(r[1]) for r in sorted(allr)]
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -372,7 +383,7 @@ def main():
     d = prof[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     kernel_names = {"vit_qkv": "vr::gemm256w_bf16_kernel<0, true, 8> (EPI_BF16; ViT qkv, 256x256 tile, one wave per SIMD)",
-                    "vit_attn": "vr::attention_kernel<72, 2, 3> (ViT self-attention, LDS-DMA staged)",
+                    "vit_attn": "vr::attention72w_kernel (ViT self-attention: persistent, one wave per SIMD, hand-ordered stream)",
                     "vit_proj": "vr::gemm256w_bf16_kernel<3, false, 6> (EPI_RESID; ViT attn proj, 256x192 tile, one wave per SIMD)",
                     "vit_fc1": "vr::gemm256w_bf16_kernel<1, true, 8> (EPI_GELU; ViT MLP fc1, 256x256 tile, one wave per SIMD)",
                     "vit_fc2": "vr::gemm256w_bf16_kernel<3, false, 6> (EPI_RESID; ViT MLP fc2, 256x192 tile, one wave per SIMD)"}
@@ -394,6 +405,28 @@ def main():
             roofline["traffic_source"] = os.path.basename(tfiles[-1]) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
     except Exception:
         pass
+    def box_id():
+        """which box, at which clocks: the pool's boxes differ by 7 % on the same library"""
+        import socket
+        import subprocess
+        info = {"host": socket.gethostname(), "device": torch.cuda.get_device_name(local_rank)}
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            info.update(cus=pr.multi_processor_count, hbm_gb=round(pr.total_memory / 2 ** 30, 1))
+            for attr in ("uuid", "pci_bus_id"):
+                if hasattr(pr, attr):
+                    info[attr] = str(getattr(pr, attr))
+        except Exception:
+            pass
+        try:
+            out_ = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20).stdout
+            js = json.loads(out_[out_.index("{"):])
+            card = js.get(f"card{local_rank}", next(iter(js.values())))
+            info["rocm_smi_after_the_timed_steps"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "power", "temperature (sensor junction)"))}
+        except Exception as e:
+            info["rocm_smi"] = repr(e)[:120]
+        return info
+
     phases = {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in prof.items()}
     # (dec_* = the decoder phase split by events BETWEEN its kernels, taken in a pass of their own; "decoder" is the undisturbed total)
@@ -416,7 +449,8 @@ def main():
         # (index_kind "filler" only when the corpus embed was skipped with --corpus-pages 0)
         "search": dict(srch, exchange=None if world == 1 else {
                            "collective": "all_gather_into_tensor of the packed [nq, k] 64-bit keys, one per search",
-                           "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": ranks_seen,
+                           "rows_per_gpu": rows_per_rank, "devices_shared": bool(shared),
                            "bytes_per_rank": args.queries * args.topk * 8, "all_gather_us": round(gather_us, 1)},
                        query_encode_per_sec=round(args.queries / q_encode_s, 1)),
         "search_filler": searches["filler"] if main_kind != "filler" else None,
@@ -425,6 +459,7 @@ def main():
         "roofline": roofline,
         "phases": phases,
         "pipelined": pipelined,
+        "box": box_id(),
     }
 
     # ---- extras (outside `value`): what the reference's own entry point sees, and real-document pages
@@ -584,6 +619,43 @@ def main():
                 "reference_in_build_container": ref_in_container}
         except Exception as e:   # the baseline is informational; never lose the GPU numbers
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
+        # north_star's "identical top-k doc IDs, cosine scores within 1e-3" against the REFERENCE ITSELF (not the port): the
+        # committed fixture of oracle/gen_golden.py --config1xl — 512 synthetic pages + the reference's own four input images x 514
+        # queries through openmatch's DRModelForInference + distributed_parallel_retrieve (top-10) — re-encoded here
+        try:
+            from tests import config1xl_util as X
+            g_, man_ = X.load_fixture()
+            corpus_, queries_ = X.corpus_and_queries(g_, man_)
+            P_ = []
+            n_syn = int(g_["n_pages"])
+            for lo in range(0, n_syn, B):
+                its_ = prepare_batch([""] * len(corpus_[lo:lo + B]), [c_["image"] for c_ in corpus_[lo:min(lo + B, n_syn)]], tok, cfg, 2048)
+                P_.append(enc.encode_items(its_).cpu())
+            for c_ in corpus_[n_syn:]:                                  # the reference's sliced pages, one per call (demo.py:44-58)
+                P_.append(enc.encode_items(prepare_batch([""], [c_["image"]], tok, cfg, 2048)).cpu())
+            P_ = torch.cat(P_)
+            qi_ = prepare_batch([q_["text"] for q_ in queries_], [None] * len(queries_), tok, cfg, 512)
+            Q_ = torch.cat([enc.encode_items(qi_[lo:lo + 64]).cpu() for lo in range(0, len(qi_), 64)])
+            ix_ = HipIndex(cfg.hidden_size, len(P_), device=local_rank)
+            ix_.add(P_.to(dev))
+            sc_, id_ = ix_.search(Q_.to(dev), int(g_["k"]))
+            ix_.close()
+            doc_ids_ = [str(x_) for x_ in g_["doc_ids"]]
+            run_ = {f"q{i}": {doc_ids_[int(j)]: float(v)} for i in range(0)}
+            sc_, id_ = sc_.cpu().numpy(), id_.cpu().numpy()
+            run_ = {f"q{i}": {doc_ids_[int(j)]: float(v) for v, j in zip(sc_[i], id_[i])} for i in range(len(Q_))}
+            st_ = X.parity_stats(g_, P_.numpy(), Q_.numpy(), run_)
+            try:
+                X.assert_bars(st_)
+                st_["bars_met"] = True
+            except AssertionError:
+                st_["bars_met"] = False
+            if isinstance(result.get("cpu_baseline"), dict):
+                result["cpu_baseline"]["reference_parity"] = st_
+            else:
+                result["reference_parity"] = st_
+        except Exception as e:
+            result["reference_parity_error"] = repr(e)
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -218,7 +218,7 @@ torch.cuda.synchronize()
 assert torch.equal(ids, fi), (rank, int((ids != fi).sum()))
 assert torch.equal(sc, fs), rank
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+print("rank", rank, "ok", "all_gathers", N_GATHER[0])
 '''
 
 
@@ -422,6 +422,13 @@ torch.cuda.set_device(rank)
 dist.init_process_group("nccl", device_id=torch.device(f"cuda:{rank}"))        # RCCL
 from visrag_amd.engine import HipIndex
 from visrag_amd.retriever import sharded_search
+N_GATHER = [0]
+_ag = dist.all_gather_into_tensor
+def _counted(out, inp, *a, **kw):
+    assert inp.is_cuda and out.is_cuda and inp.dtype == torch.int64          # device key buffers over RCCL
+    N_GATHER[0] += 1
+    return _ag(out, inp, *a, **kw)
+dist.all_gather_into_tensor = _counted
 rng = np.random.default_rng(0)
 nd, nq, dim, k = 30011, 333, 512, 10
 C = rng.standard_normal((nd, dim)).astype(np.float32); C /= np.linalg.norm(C, axis=1, keepdims=True)
@@ -452,7 +459,7 @@ for gt in (False, True):
     got = distributed_parallel_retrieve(args, k, global_topk=gt, sharded=True)
     assert got == ref and list(got) == list(ref), (rank, gt)
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+print("rank", rank, "ok", "all_gathers", N_GATHER[0])
 '''
 
 
@@ -475,6 +482,23 @@ def test_sharded_search_over_rccl(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_sharded_search_over_rccl_world_of_one(tmp_path):
+    """The RCCL code path on ONE GPU: backend "nccl" with a single rank runs the same statements as N ranks —
+    `HipIndex.search_keys` -> ONE `all_gather_into_tensor` of device int64 keys (retriever.exchange_keys) -> `vr_topk_merge_keys`
+    — for `sharded_search` and for the corpus-sharded `distributed_parallel_retrieve` (replicated and global top-k): three
+    collectives on device buffers, results equal to the unsharded search.  (Two ranks need two GPUs: the test above.)"""
+    import socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, VR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", VR_OUT=str(tmp_path))
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout
+    assert "rank 0 ok all_gathers 3" in p.stdout, p.stdout          # sharded_search + the two corpus-sharded retrieves
 
 
 @pytest.mark.parametrize("nq", [1, 40])
@@ -642,7 +666,7 @@ for k in (10, 40):                                        # fused sweep and the 
         a = open(os.path.join(out, f"ref.{rank}.{k}.{gt}.trec"), "rb").read(); b = open(os.path.join(out, f"got.{rank}.{k}.{gt}.trec"), "rb").read()
         assert a == b and len(a) > 0, (rank, k, gt)
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+print("rank", rank, "ok", "all_gathers", N_GATHER[0])
 '''
 
 

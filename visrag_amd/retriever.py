@@ -55,6 +55,12 @@ def _load_queries(args, rank="own") -> Tuple[np.ndarray, List[str], List[bool]]:
     process (`rank=None`), in sorted file order; mine[i] = query i belongs to this process's own shards."""
     parts = list_shards(args.output_dir, "query", args.process_index if rank == "own" else None)
     own = set(list_shards(args.output_dir, "query", args.process_index))
+    if rank != "own":
+        # corpus-sharded form: a query file belongs to the process its rank field maps to — the same rule as the corpus files
+        # (rank % world), so a retrieval world smaller than the encoding world drops nothing
+        dist = torch.distributed
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        own = {p for p in parts if _shard_rank(p) % world == int(args.process_index) % world}
     logger.info("query_all_partitions = %s", parts)
     reps, ids, mine = [], [], []
     for p in parts:
@@ -80,7 +86,7 @@ def _sharded_requested(args, sharded: Optional[bool]) -> bool:
     if sharded is None:
         sharded = os.environ.get("VISRAG_SHARDED_RETRIEVE", "0") not in ("", "0")
     dist = torch.distributed
-    return bool(sharded) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return bool(sharded) and dist.is_available() and dist.is_initialized()       # (a world of one too: the same code, one rank)
 
 
 def distributed_parallel_retrieve(args, topk: int, global_topk: bool = False, sharded: Optional[bool] = None,
@@ -259,8 +265,9 @@ def sharded_search(index, queries, k: int, id_offset: int = 0, group=None,
         keys = torch.from_numpy(np.ascontiguousarray(keys))
     merge_fn = merge_keys or topk_merge_keys
     dist = torch.distributed
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return merge_fn(keys.view((1,) + tuple(keys.shape)))
+    # (an initialised group of ONE rank takes the collective too: the transport runs wherever a group exists)
     return merge_fn(exchange_keys(keys, group))                              # the one collective of the path
 
 

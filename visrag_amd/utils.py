@@ -99,4 +99,9 @@ def read_shard(path: str) -> Tuple[np.ndarray, List[str]]:
 
 def list_shards(output_dir: str, dataset_type: str, rank: int = None) -> List[str]:
     pat = "embeddings.{}.rank.{}".format(dataset_type, "*" if rank is None else f"{rank}*")
-    return sorted(glob.glob(os.path.join(output_dir, pat)))
+    files = sorted(glob.glob(os.path.join(output_dir, pat)))
+    if rank is not None:
+        # the reference's glob `rank.{r}*` (dense_retriever.py:40-46) also matches ranks 10 r .. 10 r + 9 of a larger world:
+        # keep the files whose rank field IS r
+        files = [f for f in files if os.path.basename(f).split(".")[3] == str(rank)]
+    return files
