@@ -629,7 +629,8 @@ def main():
             P_ = []
             n_syn = int(g_["n_pages"])
             for lo in range(0, n_syn, B):
-                its_ = prepare_batch([""] * len(corpus_[lo:lo + B]), [c_["image"] for c_ in corpus_[lo:min(lo + B, n_syn)]], tok, cfg, 2048)
+                chunk_ = corpus_[lo:min(lo + B, n_syn)]
+                its_ = prepare_batch([""] * len(chunk_), [c_["image"] for c_ in chunk_], tok, cfg, 2048)
                 P_.append(enc.encode_items(its_).cpu())
             for c_ in corpus_[n_syn:]:                                  # the reference's sliced pages, one per call (demo.py:44-58)
                 P_.append(enc.encode_items(prepare_batch([""], [c_["image"]], tok, cfg, 2048)).cpu())
@@ -641,7 +642,6 @@ def main():
             sc_, id_ = ix_.search(Q_.to(dev), int(g_["k"]))
             ix_.close()
             doc_ids_ = [str(x_) for x_ in g_["doc_ids"]]
-            run_ = {f"q{i}": {doc_ids_[int(j)]: float(v)} for i in range(0)}
             sc_, id_ = sc_.cpu().numpy(), id_.cpu().numpy()
             run_ = {f"q{i}": {doc_ids_[int(j)]: float(v) for v, j in zip(sc_[i], id_[i])} for i in range(len(Q_))}
             st_ = X.parity_stats(g_, P_.numpy(), Q_.numpy(), run_)

@@ -218,7 +218,7 @@ torch.cuda.synchronize()
 assert torch.equal(ids, fi), (rank, int((ids != fi).sum()))
 assert torch.equal(sc, fs), rank
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok", "all_gathers", N_GATHER[0])
+print("rank", rank, "ok")
 '''
 
 
@@ -666,7 +666,7 @@ for k in (10, 40):                                        # fused sweep and the 
         a = open(os.path.join(out, f"ref.{rank}.{k}.{gt}.trec"), "rb").read(); b = open(os.path.join(out, f"got.{rank}.{k}.{gt}.trec"), "rb").read()
         assert a == b and len(a) > 0, (rank, k, gt)
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok", "all_gathers", N_GATHER[0])
+print("rank", rank, "ok")
 '''
 
 
