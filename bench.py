@@ -58,6 +58,7 @@ def main():
                     help="pages of the CPU baseline sample (one reference-sized batch of 16 by default; 64 = all of "
                          "BASELINE config 1, about 3 minutes of host time)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PIL-input and sliced-page measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc measurement of the dominant kernel's HBM traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -391,19 +392,60 @@ def main():
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches": d["launches"],
                 "flops_per_launch": d["flops"] / d["launches"], "traffic": None}
-    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
-    # the figure is the committed rocprofv3 --pmc measurement of the same kernel on the same
-    # workload (tools/pmc_traffic.sh -> profiles/rNN_traffic.json); null if none is committed.
-    try:
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
-        tj = json.load(open(tfiles[-1]))
-        key = kernel_names[dom].split(" (")[0].replace("vr::", "")
-        hit = [v for k, v in tj.items() if key in k]
-        if hit:
-            roofline["traffic"] = round(hit[0])
-            roofline["traffic_source"] = os.path.basename(tfiles[-1]) + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
-    except Exception:
+    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so rank 0 runs the SAME encode
+    # step under `rocprofv3 --pmc` in two child processes (FETCH_SIZE, then WRITE_SIZE: separate passes, kernel trace only,
+    # folded by tools/pmc_traffic.py with the guide's gfx950 correction FETCH x 2) — measured in THIS run, on this box.  Only when
+    # that fails (no rocprofv3 on the box) the committed measurement of an earlier run (profiles/rNN_traffic.json) is quoted instead.
+    def traffic_live(key):
+        import shutil
+        import subprocess
+        import tempfile
+        if args.no_pmc or world != 1 or shutil.which("rocprofv3") is None:
+            return None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_traffic
+        td = tempfile.mkdtemp(prefix="vr_pmc_", dir="/tmp")
+        vals = {}
+        try:
+            for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+                d_ = os.path.join(td, cn)
+                r_ = subprocess.run(["rocprofv3", "--pmc", cn, "--kernel-trace", "-d", d_, "-o", "enc", "--", sys.executable,
+                                     os.path.join(ROOT, "tools", "encode_only.py"), "1"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                                    capture_output=True, text=True, timeout=400)
+                if r_.returncode != 0:
+                    return None
+                hit_ = [v for k, v in pmc_traffic.per_kernel(d_).items() if key in k]
+                if not hit_:
+                    return None
+                vals[cn] = hit_[0]
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        except Exception as e_:
+            log("live PMC traffic failed:", repr(e_)[:200])
+            return None
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+
+    key = kernel_names[dom].split(" (")[0].replace("vr::", "")
+    live = traffic_live(key)
+    if live is not None:
+        roofline["traffic"] = round(live)
+        roofline["traffic_source"] = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child processes of tools/encode_only.py 1), 2 x FETCH + WRITE, per launch"
+        algo = {"vit_qkv": 2.0 * (B * 1024 * 1152 + 3456 * 1152 + B * 1024 * 3456), "vit_proj": 2.0 * (B * 1024 * 1152 + 1152 * 1152) + 8.0 * B * 1024 * 1152,
+                "vit_fc1": 2.0 * (B * 1024 * 1152 + 4304 * 1152 + B * 1024 * 4304), "vit_fc2": 2.0 * (B * 1024 * 4304 + 1152 * 4304) + 8.0 * B * 1024 * 1152,
+                "vit_attn": 2.0 * (B * 1024 * 3456 + B * 1024 * 1152)}.get(dom)
+        if algo:
+            roofline["algorithmic_bytes"] = round(algo)
+            roofline["traffic_over_algorithmic"] = round(live / algo, 3)
+    else:
+      try:
+          import glob
+          tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+          tj = json.load(open(tfiles[-1]))
+          hit = [v for k, v in tj.items() if key in k]
+          if hit:
+              roofline["traffic"] = round(hit[0])
+              roofline["traffic_source"] = os.path.basename(tfiles[-1]) + " (a COMMITTED earlier measurement: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+      except Exception:
         pass
     def box_id():
         """which box, at which clocks: the pool's boxes differ by 7 % on the same library"""

@@ -1,6 +1,6 @@
-"""tile anatomy of attention_w.hip from an AW_TIMING build: python tools/r5/attn_anatomy.py <lib>"""
+"""tile anatomy of attention_w.hip from an AW_TIMING build: python tools/attn_anatomy.py <lib>"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.gpu_util import P
 from visrag_amd import _lib

@@ -1,6 +1,6 @@
 """time vr_op_attention on the ViT shape for every library on the command line (interleaved rounds)"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests.gpu_util import P
 from visrag_amd import _lib

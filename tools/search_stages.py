@@ -1,6 +1,6 @@
 """stage times of the search for shard sizes and query counts: ND=12500,25000,100000"""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visrag_amd.engine import HipIndex
 dim = 2304

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r5/variant.sh <tag> <file.hip> [-D...]: libvisrag_hip_<tag>.so = the product objects with ONE file recompiled under extra defines
+# tools/variant.sh <tag> <file.hip> [-D...]: libvisrag_hip_<tag>.so = the product objects with ONE file recompiled under extra defines
 set -e
 cd /root/repo/visrag_amd
 TAG=$1; F=$2; shift 2

@@ -319,7 +319,7 @@ __device__ __forceinline__ void attention72w_body(const AttnArgs& p) {
     int kv_len = cur.kv_len;            // of the unit being computed (mask_half)
 
 #ifdef AW_TIMING
-    // tile anatomy (tools/r5/attn_anatomy.py; tagged builds, p.lse = u64 [unit][wave][64]): 0 start, 1 loop entry, 2 loop exit, 3 end,
+    // tile anatomy (tools/attn_anatomy.py; tagged builds, p.lse = u64 [unit][wave][64]): 0 start, 1 loop entry, 2 loop exit, 3 end,
     // 4 sum of (barrier release - arrival at the wait), 5 number of barriers, 8.. the first 24 barrier release stamps
     unsigned long long tm_start = __builtin_amdgcn_s_memtime(), tm_wait = 0, tm_loop0 = 0, tm_loop1 = 0;
     unsigned long long* tmrec = (unsigned long long*)p.lse + ((size_t)cur.u * NW + wave) * 64;

@@ -791,7 +791,9 @@ static int hp_gemm_tiles(vr_model_s* m, const void* a_hi, const void* a_lo, cons
     // [A_hi W_hi | A_lo W_hi | A_hi W_lo].  Falls back to the three in-place launches when the planes do not fit.
     const size_t plane = (size_t)T * L.n_pad;
     const int n_planes = Llo.has_w ? 3 : 2;
-    if ((const char*)a_lo == (const char*)a_hi + (size_t)T * lda * 2 && m->w_hp_planes.reserve((size_t)n_planes * plane * 4) == VR_OK) {
+    // (a Linear with a bias — none in the MiniCPM decoder — keeps the three in-place launches, whose first one adds it once: the plane
+    // sum has no bias term.  ADVICE r4)
+    if (!L.has_b && (const char*)a_lo == (const char*)a_hi + (size_t)T * lda * 2 && m->w_hp_planes.reserve((size_t)n_planes * plane * 4) == VR_OK) {
         float* part = m->w_hp_planes.as<float>();
         {
             GemmArgs a = gemm_args(a_hi, lda, L, 2 * T, part, L.n_pad);
@@ -813,11 +815,13 @@ static int hp_gemm_tiles(vr_model_s* m, const void* a_hi, const void* a_lo, cons
     }
     {
         GemmArgs a = gemm_args(a_lo, lda, L, T, out, ldo);
+        a.bias = nullptr;                                   // (added by the launch above)
         a.resid = out; a.alpha = into_resid ? alpha : 1.0f;
         HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
     }
     if (Llo.has_w) {
         GemmArgs a = gemm_args(a_hi, lda, Llo, T, out, ldo);
+        a.bias = nullptr;
         a.resid = out; a.alpha = into_resid ? alpha : 1.0f;
         HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_AUTO, s));
     }

@@ -309,7 +309,7 @@ int search_num_chunks(int64_t n_docs, int nq) {
         if (chunks < 8) chunks = 8;
         // a small shard: the smallest multiple of 8 that gives every index tile its own chunk (the chunks past the last tile are
         // empty workgroups).  Rounding DOWN — 48 chunks for the 49 tiles of an 8-way shard of the 100k index — left one chunk
-        // with two tiles and the whole sweep waiting for it: 116 us instead of 58 (round 5, tools/r5/search_stages.py).
+        // with two tiles and the whole sweep waiting for it: 116 us instead of 58 (round 5, tools/search_stages.py).
         while (chunks > 8 && chunks - 8 >= n_tiles) chunks -= 8;
         return chunks;
     }
