@@ -366,7 +366,7 @@ def main():
     # transport ran and that every GPU held a shard)
     ranks_seen = rows_per_rank = None
     if world > 1:
-        me = torch.tensor([rank, srch["rows_per_gpu"], local_rank], dtype=torch.int64, device="cpu" if shared else dev)
+        me = torch.tensor([[rank, srch["rows_per_gpu"], local_rank]], dtype=torch.int64, device="cpu" if shared else dev)
         allr = torch.empty((world, 3), dtype=torch.int64, device=me.device)
         dist.all_gather_into_tensor(allr, me)
         allr = allr.cpu().tolist()
