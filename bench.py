@@ -411,7 +411,7 @@ def main():
                 d_ = os.path.join(td, cn)
                 r_ = subprocess.run(["rocprofv3", "--pmc", cn, "--kernel-trace", "-d", d_, "-o", "enc", "--", sys.executable,
                                      os.path.join(ROOT, "tools", "encode_only.py"), "1"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
-                                    capture_output=True, text=True, timeout=400)
+                                    capture_output=True, text=True, timeout=180)
                 if r_.returncode != 0:
                     return None
                 hit_ = [v for k, v in pmc_traffic.per_kernel(d_).items() if key in k]
