@@ -387,6 +387,25 @@ def test_small_shards_are_searched_from_compacted_lists(nd, nq, dim, k):
         assert st["flagged"] < nq // 2, st
 
 
+@pytest.mark.parametrize("nd", [1000, 12500, 20480, 32768, 50000, 70001])
+@pytest.mark.parametrize("nq,dim,k", [(1, 2304, 10), (16, 2304, 10), (5, 512, 26), (9, 2560, 10)])
+def test_streaming_kernel_strip_layouts(nd, nq, dim, k):
+    """The handful-of-queries kernel (search_small.hip) gives each of its 256 workgroups ceil(nd / 256) rows (rounded to 16-row
+    strips) and its 8 waves take one strip each per round.  Shard sizes with 1 / 4 / 5 / 8 / 13 / 18 strips per workgroup
+    (full rounds, partial rounds, workgroups without rows, a ragged last strip) at three widths: ids == fp64, and the same
+    on every run."""
+    C, Q = _unit(nd, dim, 91), _unit(nq, dim, 92)
+    ix = HipIndex(dim, nd); ix.add(C)
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    assert st["uncertified"] == 0, st
+    sc2, ids2 = ix.search(Q, k)
+    assert np.array_equal(ids, ids2) and np.array_equal(sc, sc2)
+    ix.close()
+
+
 @pytest.mark.parametrize("nd,nq,dim,k", [(20000, 300, 512, 10), (3000, 7, 256, 26), (20000, 64, 512, 100), (5, 3, 64, 10)])
 def test_search_keys_and_merge_keys(nd, nq, dim, k):
     """The packed exchange format (vr_index_search_keys / vr_topk_merge_keys): one 64-bit word per result, the
