@@ -246,6 +246,28 @@ def test_build_flags_compiler_use_of_accumulation_registers():
     assert AGPR_CHECKED <= set(SOURCES) and {"gemm256w.hip", "search256w.hip"} <= AGPR_CHECKED
 
 
+def test_build_flags_mfma_operand_hazards():
+    """attention_w.hip issues its MFMAs as asm statements on arch VGPRs, so hipcc neither pads nor orders around them.  The two
+    hazards met on gfx950 must fail the build: a VALU write of an operand right in front of the MFMA that
+    reads it, and an instruction reusing an MFMA's result registers while it is still in the pipe.  The accumulate chain
+    (the next MFMA takes the whole result as its C) and the same code with enough distance are fine."""
+    from visrag_amd.build import MFMA_HAZARD_CHECKED, SOURCES, mfma_operand_hazards
+    mfma = "v_mfma_f32_16x16x32_bf16 v[20:23], v[0:3], v[4:7], v[20:23]"
+    assert mfma_operand_hazards(f"\n\t{mfma}\n\t{mfma}\n\ts_endpgm\n") == []                  # accumulate chain
+    zero_c = f"\n\tv_mov_b32 v20, 0\n\t{mfma}\n"
+    hz = mfma_operand_hazards(zero_c)
+    assert len(hz) == 1 and "v_mov_b32 v20, 0" in hz[0]
+    assert mfma_operand_hazards(f"\n\tv_mov_b32 v20, 0\n\ts_nop 1\n\t{mfma}\n") == []        # two wait states between
+    reuse = f"\n\t{mfma}\n\tv_add_f32 v21, v8, v9\n"
+    hz = mfma_operand_hazards(reuse)
+    assert len(hz) == 1 and "touches the result" in hz[0]
+    assert mfma_operand_hazards(f"\n\t{mfma}\n\ts_nop 15\n\tv_add_f32 v21, v8, v9\n") == []
+    other = "v_mfma_f32_16x16x32_bf16 v[24:27], v[20:23], v[4:7], v[24:27]"                       # result read as A too early
+    assert len(mfma_operand_hazards(f"\n\t{mfma}\n\t{other}\n")) == 1
+    assert mfma_operand_hazards(f"\n\tv_mov_b32 v20, 0\n.LBB0_1:\n\t{mfma}\n") == []            # (not modelled across labels)
+    assert MFMA_HAZARD_CHECKED <= set(SOURCES)
+
+
 def test_evisrag_rope_index_layout():
     """positions of a prompt with two images (Qwen2.5-VL get_rope_index for stills): text runs all three axes
     together, an image pins the temporal axis and walks its grid, text resumes past the largest position."""
