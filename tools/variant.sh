@@ -4,7 +4,7 @@ set -e
 cd /root/repo/visrag_amd
 TAG=$1; F=$2; shift 2
 mkdir -p build_$TAG
-FL=""; [ "$F" == "attention_w.hip" ] && FL="-fno-honor-nans"
+FL=$(cd /root/repo && python -c "from visrag_amd.build import FILE_FLAGS; print(' '.join(FILE_FLAGS.get('$F', [])))")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $FL "$@" -c csrc/$F -o build_$TAG/${F%.hip}.o
 OBJS=""
 for o in build/*.o; do b=$(basename $o); if [ "$b" == "${F%.hip}.o" ]; then OBJS="$OBJS build_$TAG/$b"; else OBJS="$OBJS $o"; fi; done

@@ -180,21 +180,111 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         char* const wl0 = smem + 2 * W_STAGE + wave * W_STAGING;
         bool plain_resid = false;
         if constexpr (EPI == EPI_RESID) plain_resid = !p.rowmap;
+        // fp32 tiles without a column edge (every encode-path shape) leave through BUFFER loads / stores: the descriptor
+        // starts at the tile's first row and ends with its last valid one (rows >= M are out of range: loads return 0,
+        // stores are dropped), a lane's offset is one VGPR per 16-row group (the hardware's range check covers the VGPR and
+        // immediate offsets, NOT the scalar one — the row step must not go there), the fragment column an immediate.
+        // No predicate, no clamp, no 64-bit address arithmetic, no branch: with the per-store `if (m < M && n < N)` of the
+        // general form below hipcc puts `s_waitcnt vmcnt(0)` in front of every piece (it counts loads exactly only in
+        // straight-line code) and every store is a `flat_store` behind an exec-mask branch.  Round 5, tools/w_anatomy.py
+        // and tools/probe_store.hip: residual epilogue 12.2 -> 10.9 us per proj / fc2 tile, fp32 epilogue -> 7.5 us.
+        // What is left is the memory system, not this code: 16 rows x 64 B per instruction (the MFMA C layout) moves
+        // 33 GB/s per CU in stores and 20 GB/s in read-modify-write even with ONE CU running, rows of >= 256 B move
+        // 118 / 33 — but with all 256 CUs in their epilogues together (equal tiles, one round = one phase) the chip
+        // gives 27 GB/s per CU in stores and 13 in read-modify-write whatever the shape (7 TB/s of HBM writes; the
+        // residual GEMMs do better than that only because part of the stream is still in the memory-side cache).
+        bool buf_tile = false;
+        if constexpr (EPI == EPI_RESID) buf_tile = plain_resid && n0 + BN <= p.N;
+        if constexpr (EPI == EPI_F32) buf_tile = !p.rowmap && !p.rowbias && n0 + BN <= p.N;
+        if constexpr (EPI == EPI_RESID || EPI == EPI_F32) {
+            if (buf_tile) {
+                constexpr int MI = 2;           // pieces of 32 rows x 16 NF columns: 8 per wave
+                // (descriptors must sit in scalar registers: whatever hipcc keeps of `p` in private memory comes back in VGPRs,
+                // and a buffer access with a VGPR descriptor is wrapped in a waterfall loop)
+                auto uni32 = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+                auto uni_ptr = [&](const void* q) {
+                    const unsigned long long a = (unsigned long long)q;
+                    return (void*)(((unsigned long long)uni32((unsigned)(a >> 32)) << 32) | uni32((unsigned)a));
+                };
+                const float alpha = __builtin_bit_cast(float, uni32(__builtin_bit_cast(unsigned, p.alpha)));
+                const unsigned ldb = uni32((unsigned)p.ldo * 4u);
+                const unsigned nrec = uni32((unsigned)min(G256_BM, p.M - m0) * ldb);
+                float* obase = (float*)p.out + (size_t)m0 * p.ldo;
+                if constexpr (EPI == EPI_F32) obase += (size_t)split * p.split_stride;
+                const auto ors = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(obase), 0, nrec, 0x00020000);
+                const bool with_bias = p.bias && (EPI == EPI_RESID || split == 0);
+                const auto brs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.bias), 0, uni32(with_bias ? (unsigned)p.N * 4u : 0u), 0x00020000);
+                const unsigned voff = (unsigned)(wm * 128 + fr) * ldb + (unsigned)(nb0 + fq * 4) * 4u;
+                f32x4 bias[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    bias[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)(nb0 + fq * 4) * 4u + j * 64, 0, 0));
+                if constexpr (EPI == EPI_RESID) {
+                    // out = resid + alpha * (acc + bias), in place; the residual of piece q + RD is in flight while piece q
+                    // is combined and stored
+                    constexpr int RD = NJ == 6 ? 3 : 2;
+                    const auto rrs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.resid + (size_t)m0 * p.ldo), 0, nrec, 0x00020000);
+                    f32x4 rs[RD + 1][MI][NF];
+                    auto load_piece = [&](int q, f32x4 (&dst)[MI][NF]) {
+                        const int h = q & 1, sg = q >> 1;
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NF; ++j)
+                                dst[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rrs, voff + (unsigned)((sg * MI + i) * 16) * ldb + (h * NF + j) * 64, 0, 0));
+                    };
+#pragma unroll
+                    for (int q = 0; q < RD; ++q) load_piece(q, rs[q]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int h = q & 1, sg = q >> 1;
+                        if (q + RD < 8) load_piece(q + RD, rs[(q + RD) % (RD + 1)]);
+                        f32x4 acc[MI][NF];
+#define W_RD(n, R, C0, C1, C2, C3) \
+                        if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
+                        W_FOR_EACH_ACC(W_RD)
+#undef W_RD
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NF; ++j) {
+                                const f32x4 v = rs[q % (RD + 1)][i][j] + alpha * (acc[i][j] + bias[h * NF + j]);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors,
+                                                                       voff + (unsigned)((sg * MI + i) * 16) * ldb + (h * NF + j) * 64, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    // fp32 outputs, incl. the split-K partial products (split s writes its own plane, the bias goes with split 0)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int h = q & 1, sg = q >> 1;
+                        f32x4 acc[MI][NF];
+#define W_RD(n, R, C0, C1, C2, C3) \
+                        if (((n) & 7) < NJ && ((n) & 7) / NF == h && ((n) >> 4) == sg) W_READ(acc[((n) >> 3) & 1][((n) & 7) % NF], C0, C1, C2, C3);
+                        W_FOR_EACH_ACC(W_RD)
+#undef W_RD
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NF; ++j)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j] + bias[h * NF + j]), ors,
+                                                                       voff + (unsigned)((sg * MI + i) * 16) * ldb + (h * NF + j) * 64, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
         if constexpr (EPI == EPI_RESID) {
-            // out = resid + alpha * (acc + bias), fp32, in place, piece by piece (below).  Addresses are clamped for
-            // rows >= M / columns >= N, the stores predicated.
-            if (plain_resid) {
+            // the general form (a column edge): out = resid + alpha * (acc + bias), fp32, in place, piece by piece.  Addresses
+            // are clamped for rows >= M / columns >= N, the stores predicated.
+            if (plain_resid && !buf_tile) {
                 constexpr int MI = 2;           // pieces of 32 rows x 16 NF columns: 8 per wave
                 const float* __restrict__ resid = p.resid;
                 float* __restrict__ out = (float*)p.out;
                 // The residual of piece q + RD is requested before piece q is combined and stored (one wave per SIMD, nothing else
-                // hides the latency).  RD = 1 is enough: round 4 measured RD = 1 .. 6 in-model on one box (the ring lives in the
-                // K-loop's dead fragment registers) — proj 3.31-3.36 ms, fc2 7.89-8.00 ms per step for every depth — while the
-                // same epilogue WITHOUT its reads runs proj at 2.35 / fc2 at 7.02 and WITHOUT its stores at 2.50 / 6.94, and an
-                // early touch of the residual lines into the L2 is slower (3.53 / 8.42).  So the read-modify-write is paced by
-                // the HBM moving 302 MB per launch in the epilogue phases of the rounds (all CUs leave their K-loops together:
-                // ~3.8 TB/s of mixed reads and writes there, nothing during the K-loops), not by the depth of this wave's
-                // prefetch; overlapping it needs the NEXT tile's K-loop on the same CU, i.e. a second accumulator set.
+                // hides the latency); only tiles with a column edge come here (see the buffer form above for what paces it).
 #ifndef VR_W_RESID_DEPTH
 #define VR_W_RESID_DEPTH 1
 #endif
@@ -251,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
-        if (!plain_resid) {
+        if (!plain_resid && !buf_tile) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 constexpr int MI = 2;
