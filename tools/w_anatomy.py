@@ -14,8 +14,11 @@ s = torch.cuda.current_stream().cuda_stream
 shapes = [(32768, 3456, 1152, 0), (32768, 4352, 1152, 1)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]]
-for (M, N, K, epi) in shapes:
+for sh in shapes:
+    M, N, K, epi = sh[:4]
     variant, BN = (13, 192) if (epi == 3 and N % 192 == 0) else (12, 256)      # the product's choice for the N = 1152 residual GEMMs
+    if len(sh) > 4:
+        variant, BN = sh[4], (192 if sh[4] == 13 else 256)
     Np = (N + BN - 1) // BN * BN
     A = torch.randn((M, K), device="cuda").to(torch.bfloat16)
     W = (torch.randn((Np, K), device="cuda") * 0.05).to(torch.bfloat16)
