@@ -193,19 +193,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // 118 / 33 — but with all 256 CUs in their epilogues together (equal tiles, one round = one phase) the chip
         // gives 27 GB/s per CU in stores and 13 in read-modify-write whatever the shape (7 TB/s of HBM writes; the
         // residual GEMMs do better than that only because part of the stream is still in the memory-side cache).
+        // (descriptors must sit in scalar registers: whatever hipcc keeps of `p` in private memory comes back in VGPRs,
+        // and a buffer access with a VGPR descriptor is wrapped in a waterfall loop)
+        auto uni32 = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+        auto uni_ptr = [&](const void* q) {
+            const unsigned long long a = (unsigned long long)q;
+            return (void*)(((unsigned long long)uni32((unsigned)(a >> 32)) << 32) | uni32((unsigned)a));
+        };
         bool buf_tile = false;
         if constexpr (EPI == EPI_RESID) buf_tile = plain_resid && n0 + BN <= p.N;
         if constexpr (EPI == EPI_F32) buf_tile = !p.rowmap && !p.rowbias && n0 + BN <= p.N;
         if constexpr (EPI == EPI_RESID || EPI == EPI_F32) {
             if (buf_tile) {
                 constexpr int MI = 2;           // pieces of 32 rows x 16 NF columns: 8 per wave
-                // (descriptors must sit in scalar registers: whatever hipcc keeps of `p` in private memory comes back in VGPRs,
-                // and a buffer access with a VGPR descriptor is wrapped in a waterfall loop)
-                auto uni32 = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-                auto uni_ptr = [&](const void* q) {
-                    const unsigned long long a = (unsigned long long)q;
-                    return (void*)(((unsigned long long)uni32((unsigned)(a >> 32)) << 32) | uni32((unsigned)a));
-                };
                 const float alpha = __builtin_bit_cast(float, uni32(__builtin_bit_cast(unsigned, p.alpha)));
                 const unsigned ldb = uni32((unsigned)p.ldo * 4u);
                 const unsigned nrec = uni32((unsigned)min(G256_BM, p.M - m0) * ldb);
@@ -342,6 +342,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         if (!plain_resid && !buf_tile) {
+            // (lookup-free bf16 epilogues: the tile's output rows behind one descriptor, the wave's bias columns loaded once —
+            // an empty descriptor without a bias, ending at N: see gemm_epilogue_tile_lds_plain_buf)
+            const unsigned ldo2 = uni32((unsigned)p.ldo * 2u);
+            const auto ors16 = __builtin_amdgcn_make_buffer_rsrc(uni_ptr((const char*)p.out + (size_t)m0 * p.ldo * 2), 0,
+                                                                 uni32((unsigned)min(G256_BM, p.M - m0) * ldo2), 0x00020000);
+            f32x4 biasw[NJ];
+            if constexpr (PLAIN && NF == 4 && EPI != EPI_ROPE) {
+                const auto brs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.bias), 0, uni32(p.bias ? (unsigned)p.N * 4u : 0u), 0x00020000);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    biasw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)(nb0 + fq * 4) * 4u + j * 64, 0, 0));
+            }
+            (void)ors16; (void)ldo2; (void)biasw;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 constexpr int MI = 2;
@@ -390,7 +403,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 if constexpr (NF == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE)) {
                     if constexpr (PLAIN) {
-                        gemm_epilogue_tile_lds_plain<EPI, MI>(acc, p, mr, nb, lane, wl0);
+                        f32x4 b4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b4[j] = EPI == EPI_ROPE ? f32x4{0.f, 0.f, 0.f, 0.f} : biasw[h * NF + j];
+                        gemm_epilogue_tile_lds_plain_buf<EPI, MI>(acc, b4, p, ors16, (unsigned)(wm * 128 + sg * 32) * ldo2, ldo2, mr, nb, lane, wl0);
                         done = true;
                     } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
                         gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl0);

@@ -56,7 +56,11 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 x) {
     const f32x4 hx = x * c4(0.5f);
     return __builtin_elementwise_fma(hx, e, hx);
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// silu(x) = x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division: `x / (1 + e^-x)` costs a dozen
+// instructions per value (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup) — 1 500 of the 2 500 per lane and tile
+// of the SwiGLU epilogue; the result is rounded to bf16 right after.  (x = -inf would give NaN where the division gave -0;
+// finite x of any size is fine: e^-x overflows to inf, the reciprocal is 0.)
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // Epilogue of one 16-row fragment strip: this lane holds out[m][nb + j*16 + fq*4 + r], j = 0..3.
 // `nb` is the first of the wave's 64 output columns.
@@ -409,6 +413,119 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4]
             const int m = mrow0 + row, n = nb + c * 8;
             if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n) = d[it];
         }
+    }
+}
+
+// The lookup-free epilogue as the one-wave-per-SIMD kernel runs it (round 5): the bias of the wave's columns is loaded ONCE per
+// tile by the caller (a buffer load whose descriptor is empty without a bias and ends at N: no branch, no clamp), and the
+// rows leave through a BUFFER store — the descriptor covers the tile's valid rows (rows >= M are dropped by the range
+// check), a column past N turns the lane's offset out of range.  No predicates, no exec-mask branches, no 64-bit address
+// arithmetic: the general form above spends ~1 400 instructions per lane and tile, a third of them on exactly that.
+//   ors: output rows [m0, min(m0 + 256, M)) of the tile;  row_off: byte offset of the piece's first row in it
+template <int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue_tile_lds_plain_buf(f32x4 (&acc)[MI][4], f32x4 (&bias)[4], const GemmArgs& p,
+                                                                 __amdgpu_buffer_rsrc_t ors, unsigned row_off, unsigned ldo_bytes,
+                                                                 int mrow0, int nb, int lane, char* wl_generic) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE, "bf16 outputs only");
+    typedef __attribute__((address_space(3))) char* lds_p;
+    const lds_p wl = (lds_p)VR_LDS(wl_generic);
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = i * 16 + fr;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const f32x4 g = acc[i][2 * jj] + bias[2 * jj], u = acc[i][2 * jj + 1] + bias[2 * jj + 1];
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(silu(g[r]) * u[r]);
+                const int c = jj * 2 + (fq >> 1);
+                *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4) + (fq & 1) * 8) = o;
+            }
+        }
+    } else {
+        if constexpr (EPI == EPI_ROPE) {
+            if (nb < p.rope_cols && nb < p.N) {        // (wave-uniform) this 64-column block is a q or k head
+                int pos[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) pos[i] = p.rope_pos[min(mrow0 + i * 16 + fr, p.M - 1)];
+#pragma unroll
+                for (int c = 0; c < MI; c += 2) {
+                    f32x4 cs[2][2], sn[2][2];
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const float* tab = p.rope_table + (size_t)pos[c + ii] * 64;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            cs[ii][j] = *reinterpret_cast<const f32x4*>(tab + j * 16 + fq * 4);
+                            sn[ii][j] = *reinterpret_cast<const f32x4*>(tab + 32 + j * 16 + fq * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 x1 = acc[c + ii][j], x2 = acc[c + ii][j + 2];
+                            acc[c + ii][j] = x1 * cs[ii][j] - x2 * sn[ii][j];
+                            acc[c + ii][j + 2] = x2 * cs[ii][j] + x1 * sn[ii][j];
+                        }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_BF16) {
+            if (nb < p.col_scale_n) {                  // (wave-uniform: this 64-column block is scaled — the ViT's q heads)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = (acc[i][j] + bias[j]) * p.col_scale;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] += bias[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j];
+                if constexpr (EPI == EPI_GELU) v = gelu_erf4(v + bias[j]);
+                const bf16x4 o = __builtin_convertvector(v, bf16x4);       // two v_cvt_pk_bf16_f32
+                const int c = j * 2 + (fq >> 1);
+                *reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+            }
+        }
+    }
+    // row-wise read-back (same wave: its LDS operations execute in order), full-line buffer stores
+    constexpr unsigned OOR = 0x80000000u;              // beyond every descriptor
+    if constexpr (EPI == EPI_SWIGLU) {
+        u32x4 d[MI];
+#pragma unroll
+        for (int it = 0; it < MI; ++it) {
+            const int row = it * 16 + (lane >> 2), c = lane & 3;
+            d[it] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 3)) << 4));
+        }
+        const int n = nb / 2 + (lane & 3) * 8;
+        const unsigned cofs = 2 * n < p.N ? (unsigned)n * 2u : OOR;
+#pragma unroll
+        for (int it = 0; it < MI; ++it)
+            __builtin_amdgcn_raw_buffer_store_b128(d[it], ors, row_off + (unsigned)(it * 16 + (lane >> 2)) * ldo_bytes + cofs, 0, 0);
+    } else {
+        u32x4 d[MI * 2];
+#pragma unroll
+        for (int it = 0; it < MI * 2; ++it) {
+            const int row = it * 8 + (lane >> 3), c = lane & 7;
+            d[it] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(wl + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+        const int n = nb + (lane & 7) * 8;
+        const unsigned cofs = n < p.N ? (unsigned)n * 2u : OOR;
+#pragma unroll
+        for (int it = 0; it < MI * 2; ++it)
+            __builtin_amdgcn_raw_buffer_store_b128(d[it], ors, row_off + (unsigned)(it * 8 + (lane >> 3)) * ldo_bytes + cofs, 0, 0);
     }
 }
 
