@@ -354,7 +354,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < NJ; ++j)
                     biasw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)(nb0 + fq * 4) * 4u + j * 64, 0, 0));
             }
-            (void)ors16; (void)ldo2; (void)biasw;
+            // (row bias: only the bf16 form carries one, and only when a tile cannot wrap around its period — launch_w)
+            const bool rb_on = EPI == EPI_BF16 && PLAIN && p.rowbias != nullptr;
+            const auto rbrs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.rowbias), 0,
+                                                                uni32(rb_on ? (unsigned)p.rowbias_period * (unsigned)p.rowbias_ld * 4u : 0u), 0x00020000);
+            const unsigned rb_row0 = rb_on ? uni32((unsigned)(m0 % p.rowbias_period)) : 0u;
+            (void)ors16; (void)ldo2; (void)biasw; (void)rbrs; (void)rb_row0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 constexpr int MI = 2;
@@ -406,7 +411,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         f32x4 b4[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) b4[j] = EPI == EPI_ROPE ? f32x4{0.f, 0.f, 0.f, 0.f} : biasw[h * NF + j];
-                        gemm_epilogue_tile_lds_plain_buf<EPI, MI>(acc, b4, p, ors16, (unsigned)(wm * 128 + sg * 32) * ldo2, ldo2, mr, nb, lane, wl0);
+                        gemm_epilogue_tile_lds_plain_buf<EPI, MI>(acc, b4, p, ors16, (unsigned)(wm * 128 + sg * 32) * ldo2, ldo2, mr, nb, lane, wl0,
+                                                                  rbrs, (rb_row0 + (unsigned)(wm * 128 + sg * 32)) * (unsigned)p.rowbias_ld * 4u);
                         done = true;
                     } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
                         gemm_epilogue_tile_lds<EPI, MI>(acc, p, mr, nb, lane, wl0);

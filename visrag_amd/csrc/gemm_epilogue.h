@@ -422,10 +422,14 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4]
 // check), a column past N turns the lane's offset out of range.  No predicates, no exec-mask branches, no 64-bit address
 // arithmetic: the general form above spends ~1 400 instructions per lane and tile, a third of them on exactly that.
 //   ors: output rows [m0, min(m0 + 256, M)) of the tile;  row_off: byte offset of the piece's first row in it
+//   rbrs / rb_off (bf16 epilogue only): the per-row bias table f32 [period][rowbias_ld] behind a descriptor and the byte offset of
+//   the piece's first row in it — the launcher admits a row bias here only when period % 256 == 0 (a tile never wraps) and
+//   rowbias_cols % 64 == 0; the caller passes an EMPTY descriptor otherwise (loads return 0)
 template <int EPI, int MI>
 __device__ __forceinline__ void gemm_epilogue_tile_lds_plain_buf(f32x4 (&acc)[MI][4], f32x4 (&bias)[4], const GemmArgs& p,
                                                                  __amdgpu_buffer_rsrc_t ors, unsigned row_off, unsigned ldo_bytes,
-                                                                 int mrow0, int nb, int lane, char* wl_generic) {
+                                                                 int mrow0, int nb, int lane, char* wl_generic,
+                                                                 __amdgpu_buffer_rsrc_t rbrs, unsigned rb_off) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE, "bf16 outputs only");
     typedef __attribute__((address_space(3))) char* lds_p;
     const lds_p wl = (lds_p)VR_LDS(wl_generic);
@@ -474,6 +478,19 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain_buf(f32x4 (&acc)[MI
             }
         }
         if constexpr (EPI == EPI_BF16) {
+            if (p.rowbias && nb < p.rowbias_cols) {    // (wave-uniform: the resampler's k half gets pos_k[row % patches])
+                f32x4 rb[MI][4];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        rb[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            rbrs, rb_off + (unsigned)(i * 16 + fr) * (unsigned)p.rowbias_ld * 4u + (unsigned)(nb + j * 16 + fq * 4) * 4u, 0, 0));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += rb[i][j];
+            }
             if (nb < p.col_scale_n) {                  // (wave-uniform: this 64-column block is scaled — the ViT's q heads)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
