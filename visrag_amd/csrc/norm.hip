@@ -11,58 +11,79 @@ namespace vr {
 
 constexpr int NORM_MAXV = 14;   // float4 per lane at most: rows up to 64*4*14 = 3584 columns (the generator's hidden size)
 constexpr int NORM_STDV = 10;   // the encoder's rows (<= 2560 columns) keep the 10-register form: 14 costs its LayerNorm 14 %
+constexpr int NORM_VITV = 5;    // the ViT's rows (1152 columns = 4.5 x 256): half the loop bodies of the 10-register form are masked off
 
-template <bool RMS, int MAXV = NORM_STDV>
+// RPW rows per wave (adjacent): gamma / beta are loaded once per wave pass instead of once per row — for the ViT's 1152-column
+// rows they are 9.2 KB of L1 / L2 reads per row next to the row's own 4.6 KB.
+template <bool RMS, int MAXV = NORM_STDV, int RPW = 1>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int rows, int dim, int ldx,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ b, float eps,
                                                    bf16_t* __restrict__ out, int ldo) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int nv = dim >> 2;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * ldx);
-    f32x4 v[MAXV];
-    float s = 0.f;
+    f32x4 v[RPW][MAXV];
+    float mu[RPW], rstd[RPW];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + i * 64;
-        v[i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (RMS) s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-        else s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    }
-    s = wave_sum(s);
-    float mu = 0.f, rstd;
-    if constexpr (RMS) {
-        rstd = rsqrtf(s / dim + eps);
-    } else {
-        mu = s / dim;
-        float q = 0.f;
+    for (int r = 0; r < RPW; ++r) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)min(row0 + r, rows - 1) * ldx);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mu; q += d * d; }
-            }
+            v[r][i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        q = wave_sum(q);
-        rstd = 1.0f / sqrtf(q / dim + eps);
     }
-    bf16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if constexpr (RMS) s += v[r][i][0] * v[r][i][0] + v[r][i][1] * v[r][i][1] + v[r][i][2] * v[r][i][2] + v[r][i][3] * v[r][i][3];
+            else s += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3];
+        }
+        s = wave_sum(s);
+        mu[r] = 0.f;
+        if constexpr (RMS) {
+            rstd[r] = rsqrtf(s / dim + eps);
+        } else {
+            mu[r] = s / dim;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = lane + i * 64;
+                if (c < nv) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mu[r]; q += d * d; }
+                }
+            }
+            q = wave_sum(q);
+            rstd[r] = 1.0f / sqrtf(q / dim + eps);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const f32x4 ww = reinterpret_cast<const f32x4*>(w)[c];
-            f32x4 y = (v[i] - mu) * rstd * ww;
-            if constexpr (!RMS) y += reinterpret_cast<const f32x4*>(b)[c];
-            bf16x4 o;
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!RMS) bb = reinterpret_cast<const f32x4*>(b)[c];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(y[r]);
-            reinterpret_cast<bf16x4*>(orow)[c] = o;
+            for (int r = 0; r < RPW; ++r) {
+                if (row0 + r < rows) {
+                    f32x4 y = (v[r][i] - mu[r]) * rstd[r] * ww;
+                    if constexpr (!RMS) y += bb;
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(y[e]);
+                    reinterpret_cast<bf16x4*>(out + (size_t)(row0 + r) * ldo)[c] = o;
+                }
+            }
         } else if (c * 4 < ldo) {
-            reinterpret_cast<bf16x4*>(orow)[c] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                if (row0 + r < rows) reinterpret_cast<bf16x4*>(out + (size_t)(row0 + r) * ldo)[c] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         }
     }
 }
@@ -71,7 +92,12 @@ hipError_t launch_layernorm(const float* x, int rows, int dim, int ldx, const fl
                             float eps, void* out, int ldo, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (dim % 4 || ldo % 4 || ldx % 4 || ldo > 64 * 4 * NORM_MAXV || dim > ldo || dim > ldx) return hipErrorInvalidValue;
-    if (ldo <= 64 * 4 * NORM_STDV)
+#ifndef VR_NORM_VITV
+#define VR_NORM_VITV 1
+#endif
+    if (VR_NORM_VITV && ldo <= 64 * 4 * NORM_VITV)
+        hipLaunchKernelGGL((norm_kernel<false, NORM_VITV, 2>), dim3((rows + 7) / 8), dim3(256), 0, s, x, rows, dim, ldx, w, b, eps, (bf16_t*)out, ldo);
+    else if (ldo <= 64 * 4 * NORM_STDV)
         hipLaunchKernelGGL((norm_kernel<false, NORM_STDV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, b, eps, (bf16_t*)out, ldo);
     else
         hipLaunchKernelGGL((norm_kernel<false, NORM_MAXV>), dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, dim, ldx, w, b, eps, (bf16_t*)out, ldo);
