@@ -34,7 +34,11 @@
 //     the kernel no faster: with a static split the slowest workgroup sets the end (CUs differ by 8 %,
 //     XCDs by 2.5 %), and per-XCD atomic cursors cost as much (index arithmetic and the LDS mailbox between
 //     K-steps) as they balance: ViT qkv 227 vs 221 us, proj 109 vs 102.  The hardware dispatcher already
-//     does that balancing for a one-tile-per-workgroup grid.
+//     does that balancing for a one-tile-per-workgroup grid.  Round 5 tried the middle: PAIRS of tiles per workgroup for
+//     whole rounds of the CUs, the rest one tile each — correct, qkv -1.7 %, but the step +1.6 % (the residual GEMMs' first
+//     epilogue queues behind the second tile's HBM operand loads; and a prologue is a wait, not work: under the power cap the
+//     clock takes such cycles back — DESIGN.md 5.2, ledger 50).  What did pay in round 5 was executing less in the epilogues
+//     (buffer descriptors instead of predicates, branches and 64-bit address arithmetic: gemm256w_kernel.h, gemm_epilogue.h).
 //
 // NJ = 16-column fragments per wave: 8 -> 256 x 256 tile, 6 -> 256 x 192 tile (N = 1152 = 6 x 192: SigLIP proj / fc2,
 // residual epilogue only).  Slot s = strip * NJ + fragment numbers the MFMAs of a phase; the numbers in the
