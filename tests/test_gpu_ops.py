@@ -63,8 +63,8 @@ def test_gemm_identity_asymmetric():
 
 
 @pytest.mark.parametrize("variant", [0, 3, 9, 12])
-def test_gemm_epilogues(variant):
-    M, N, K = 200, 256, 128
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (300, 384, 64)])     # (384: the 256-wide tiles' column edge — the general forms)
+def test_gemm_epilogues(variant, M, N, K):
     A, W, b = _bf(_rand((M, K), 4)), _bf(_rand((N, K), 5, 0.2)), _rand((N,), 6)
     acc = A.float() @ W.float().T
     Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)

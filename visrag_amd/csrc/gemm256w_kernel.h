@@ -80,22 +80,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int m0, n0, split;
     coords(my_first, m0, n0, split);
     unsigned curA = tile_off_a(m0, split), curW = tile_off_w(n0, split);
-#if defined(VR_W_RESID_TOUCH) && VR_W_RESID_TOUCH
-    // A/B knob: the fp32 residual tile this workgroup will read-modify-write is asked for NOW (one dword per 128-B line,
-    // LDS-DMA'd into the wave's staging area: no register, oldest loads of the wave, so every later vmcnt wait covers them)
-    if constexpr (EPI == EPI_RESID) {
-        if (!p.rowmap) {
-            char* const dump = smem + 2 * W_STAGE + wave * W_STAGING;
-            constexpr int LPR = BN * 4 / 128;                       // 128-B lines per tile row
-#pragma unroll
-            for (int i = 0; i < (64 * LPR + 63) / 64; ++i) {
-                const int li = i * 64 + lane, row = min(m0 + wave * 64 + li / LPR, p.M - 1), seg = li % LPR;
-                const float* a = p.resid + (size_t)row * p.ldo + min(n0 + seg * 32, p.N - 4);
-                __builtin_amdgcn_global_load_lds(VR_GLOBAL(a), VR_LDS(dump), 4, 0, 0);
-            }
-        }
-    }
-#endif
 
     // ---- prologue: K-steps 0 and 1 in flight, the accumulators zeroed under their latency (256 register writes:
     //      half a microsecond), k-half-0 fragments of step 0 requested
@@ -285,11 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float* __restrict__ out = (float*)p.out;
                 // The residual of piece q + RD is requested before piece q is combined and stored (one wave per SIMD, nothing else
                 // hides the latency); only tiles with a column edge come here (see the buffer form above for what paces it).
-#ifndef VR_W_RESID_DEPTH
-#define VR_W_RESID_DEPTH 1
-#endif
-                // (the 256-column tile keeps 256 accumulators: a ring deeper than 3 of its 32-register pieces does not fit beside them)
-                constexpr int RD = NJ == 6 ? VR_W_RESID_DEPTH : (VR_W_RESID_DEPTH < 3 ? VR_W_RESID_DEPTH : 3);
+                constexpr int RD = 1;
                 f32x4 rs[RD + 1][MI][NF];
                 auto load_piece = [&](int q, f32x4 (&dst)[MI][NF]) {
                     const int h = q & 1, sg = q >> 1;
@@ -298,11 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const size_t ro = (size_t)min(mrow0 + (sg * MI + i) * 16 + fr, p.M - 1) * p.ldo;
 #pragma unroll
                         for (int j = 0; j < NF; ++j) {
-#if defined(VR_W_RESID_DIAG) && VR_W_RESID_DIAG == 1      // diagnostic build: no residual reads (WRONG results; what would hiding them buy?)
-                            dst[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; (void)ro;
-#else
                             dst[i][j] = *reinterpret_cast<const f32x4*>(resid + ro + min(nb0 + (h * NF + j) * 16 + fq * 4, p.N - 4));
-#endif
                         }
                     }
                 };
@@ -327,14 +303,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                         for (int j = 0; j < NF; ++j) {
                             const int n = nb0 + (h * NF + j) * 16 + fq * 4;
-#if defined(VR_W_RESID_DIAG) && VR_W_RESID_DIAG == 2      // diagnostic build: no stores (WRONG results)
-                            const f32x4 vv = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
-                            if (m < p.M && n < p.N && vv[0] == 123456.78f)
-                                *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = vv;
-#else
                             if (m < p.M && n < p.N)
                                 *reinterpret_cast<f32x4*>(out + (size_t)m * p.ldo + n) = rs[q % (RD + 1)][i][j] + p.alpha * (acc[i][j] + bias[h * NF + j]);
-#endif
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
