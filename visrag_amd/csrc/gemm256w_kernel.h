@@ -329,7 +329,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const auto rbrs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.rowbias), 0,
                                                                 uni32(rb_on ? (unsigned)p.rowbias_period * (unsigned)p.rowbias_ld * 4u : 0u), 0x00020000);
             const unsigned rb_row0 = rb_on ? uni32((unsigned)(m0 % p.rowbias_period)) : 0u;
-            (void)ors16; (void)ldo2; (void)biasw; (void)rbrs; (void)rb_row0;
+            int posw[8];               // EPI_ROPE: the positions of this lane's eight rows (row = wm * 128 + t * 16 + fr), one round trip per tile
+#pragma unroll
+            for (int t = 0; t < 8; ++t) posw[t] = 0;
+            if constexpr (EPI == EPI_ROPE && PLAIN) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) posw[t] = p.rope_pos[min(mrow0 + t * 16 + fr, p.M - 1)];
+            }
+            // ... and their cos / sin rows, a strip group (two rows per lane) ahead of the piece that rotates with them
+            f32x4 rt[2][2][4];
+            auto load_rope = [&](int sg, f32x4 (&d)[2][4]) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float* tab = p.rope_table + (size_t)posw[sg * 2 + i] * 64 + fq * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(tab + j * 16);       // cos 0:16, cos 16:32, sin 0:16, sin 16:32
+                }
+            };
+            if constexpr (EPI == EPI_ROPE && PLAIN) load_rope(0, rt[0]);
+            (void)ors16; (void)ldo2; (void)biasw; (void)rbrs; (void)rb_row0; (void)posw; (void)rt;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 constexpr int MI = 2;
@@ -381,7 +399,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         f32x4 b4[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) b4[j] = EPI == EPI_ROPE ? f32x4{0.f, 0.f, 0.f, 0.f} : biasw[h * NF + j];
-                        gemm_epilogue_tile_lds_plain_buf<EPI, MI>(acc, b4, p, ors16, (unsigned)(wm * 128 + sg * 32) * ldo2, ldo2, mr, nb, lane, wl0,
+                        if constexpr (EPI == EPI_ROPE) { if (h == 0 && sg + 1 < 4) load_rope(sg + 1, rt[(sg + 1) & 1]); }
+                        gemm_epilogue_tile_lds_plain_buf<EPI, MI>(acc, b4, p, ors16, (unsigned)(wm * 128 + sg * 32) * ldo2, ldo2, rt[sg & 1], nb, lane, wl0,
                                                                   rbrs, (rb_row0 + (unsigned)(wm * 128 + sg * 32)) * (unsigned)p.rowbias_ld * 4u);
                         done = true;
                     } else if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {

@@ -428,7 +428,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain(f32x4 (&acc)[MI][4]
 template <int EPI, int MI>
 __device__ __forceinline__ void gemm_epilogue_tile_lds_plain_buf(f32x4 (&acc)[MI][4], f32x4 (&bias)[4], const GemmArgs& p,
                                                                  __amdgpu_buffer_rsrc_t ors, unsigned row_off, unsigned ldo_bytes,
-                                                                 int mrow0, int nb, int lane, char* wl_generic,
+                                                                 const f32x4 (&rope)[MI][4], int nb, int lane, char* wl_generic,
                                                                  __amdgpu_buffer_rsrc_t rbrs, unsigned rb_off) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE, "bf16 outputs only");
     typedef __attribute__((address_space(3))) char* lds_p;
@@ -450,31 +450,18 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_plain_buf(f32x4 (&acc)[MI
         }
     } else {
         if constexpr (EPI == EPI_ROPE) {
+            // rope[i] = cos[0:16 | 16:32] and sin[0:16 | 16:32] of row i's position at this lane's four columns — loaded by the caller a
+            // strip group ahead (the same for every head): with the position and table loads inside this branch every piece waited
+            // for a round trip of its own (and for the previous piece's stores: one counter) — 8 per tile, ~11 us of a 61 us tile
             if (nb < p.rope_cols && nb < p.N) {        // (wave-uniform) this 64-column block is a q or k head
-                int pos[MI];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) pos[i] = p.rope_pos[min(mrow0 + i * 16 + fr, p.M - 1)];
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int c = 0; c < MI; c += 2) {
-                    f32x4 cs[2][2], sn[2][2];
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const float* tab = p.rope_table + (size_t)pos[c + ii] * 64;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            cs[ii][j] = *reinterpret_cast<const f32x4*>(tab + j * 16 + fq * 4);
-                            sn[ii][j] = *reinterpret_cast<const f32x4*>(tab + 32 + j * 16 + fq * 4);
-                        }
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 x1 = acc[i][j], x2 = acc[i][j + 2];
+                        acc[i][j] = x1 * rope[i][j] - x2 * rope[i][2 + j];
+                        acc[i][j + 2] = x2 * rope[i][j] + x1 * rope[i][2 + j];
                     }
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const f32x4 x1 = acc[c + ii][j], x2 = acc[c + ii][j + 2];
-                            acc[c + ii][j] = x1 * cs[ii][j] - x2 * sn[ii][j];
-                            acc[c + ii][j + 2] = x2 * cs[ii][j] + x1 * sn[ii][j];
-                        }
-                }
             }
         }
         if constexpr (EPI == EPI_BF16) {
