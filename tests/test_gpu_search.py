@@ -348,6 +348,23 @@ def test_exact_pass_alone_matches_oracle(nd, nq, dim, k):
     assert ix.search_stats()["uncertified"] == 0
 
 
+def test_flagged_queries_walk_several_windows_of_the_score_buffer():
+    """The fallback passes hold at most 512 MiB of fp32 score rows: `slots` = 2^27 / rows flagged queries per window, walked in
+    a loop of launches (engine.hip: vr_index_search).  300 000 rows x 500 flagged queries = two windows for the band GEMM +
+    band selection and for the exact pass (every band is the whole index: band pass hands on to the exact pass): ids ==
+    fp64 for every query, whichever window it fell into."""
+    nd, nq, dim, k = 300000, 500, 64, 10
+    C, Q = _unit(nd, dim, 45), _unit(nq, dim, 46)
+    ix = HipIndex(dim, nd); ix.add(C)
+    ix.set_search_eps(100.0)
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    assert st["flagged"] == nq and st["exact_pass"] == nq and st["uncertified"] == 0, st
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    ix.close()
+
+
 def test_random_index_is_certified_without_the_exact_pass():
     """BASELINE config 3's index (random unit rows, 100k x 2304, 1k queries, top-10) under the rigorous bound:
     every query certified from its candidate lists — the exact pass stays idle (its cost is what the
