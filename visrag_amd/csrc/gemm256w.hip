@@ -98,7 +98,7 @@ static hipError_t launch_w(const GemmArgs& a, hipStream_t s) {
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SWIGLU || EPI == EPI_ROPE) {
         // (a row bias rides the lookup-free bf16 form when no tile can wrap around its period and it covers whole 64-column blocks:
         // the resampler's k | v in-projection, pos_k[row % 1024] on the k half)
-        const bool rb_ok = !a.rowbias || (EPI == EPI_BF16 && a.rowbias_period % G256_BM == 0 && a.rowbias_cols % 64 == 0 && a.rowbias_cols <= a.rowbias_ld &&
+        const bool rb_ok = !a.rowbias || (EPI == EPI_BF16 && a.rowbias_period > 0 && a.rowbias_period % G256_BM == 0 && a.rowbias_cols % 64 == 0 && a.rowbias_cols <= a.rowbias_ld &&
                                           (size_t)a.rowbias_period * a.rowbias_ld * 4 < (1ull << 32));
         if (!a.rowmap && rb_ok && (a.N & 7) == 0 && (a.ldo & 7) == 0) return launch_wp<EPI, true, 8>(a, s);
     }
