@@ -270,6 +270,45 @@ def test_retrieve_trec_equals_reference(golden_dir, tmp_path):
     assert all(len(v) == 5 and set(v) <= set(run[q]) for q, v in top.items())
 
 
+def test_retrieve_phase_equals_the_reference_drivers_output(golden_dir, tmp_path):
+    """Row f2 on the GPU: the statements of driver/eval.py's retrieve phase (:210-304 — distributed_parallel_retrieve,
+    save_as_trec, glob + load_from_trec, pytrec_eval ndcg_cut.10 / recall.10, eval_mrr(...)['all']) with the swapped
+    imports of INTEGRATION.md, over the real HipIndex.  Against what the REFERENCE's own eval.py wrote and printed for the
+    same shards and qrels (tests/golden/eval_driver.npz, oracle/gen_golden.py --evaldriver): the TREC lines (scores to 1e-5:
+    fp32 dots in a different summation order), test_result.log and the three metric lines, character for character."""
+    import glob, types
+    from test_cpu_eval_dropin import _write_case
+    from visrag_amd import pytrec_eval
+    from visrag_amd.retriever import distributed_parallel_retrieve
+    from visrag_amd.utils import eval_mrr, load_from_trec, save_as_trec
+    g = np.load(os.path.join(golden_dir, "eval_driver.npz"))
+    out = str(tmp_path)
+    qrels_path = _write_case(out, golden_dir)
+    assert open(qrels_path).read() == str(g["qrels"])
+    qrels = {}
+    for ln in open(qrels_path).read().strip().split("\n")[1:]:                       # load_beir_qrels, eval.py:58-68
+        q, d, r = ln.split("\t")
+        qrels.setdefault(q, {})[d] = int(r)
+    args = types.SimpleNamespace(output_dir=out, process_index=0, world_size=1, retrieve_depth=10, device="cuda:0")
+    run = distributed_parallel_retrieve(args=args, topk=args.retrieve_depth)
+    save_as_trec(run, os.path.join(out, "test.0.trec"))
+    got = [l.split("\t") for l in open(os.path.join(out, "test.0.trec")).read().strip().split("\n")]
+    ref = [l.split("\t") for l in str(g["trec"]).strip().split("\n")]
+    assert len(got) == len(ref) > 0
+    for a, b in zip(got, ref):
+        assert a[:4] == b[:4] and a[5] == b[5] and abs(float(a[4]) - float(b[4])) < 1e-5, (a, b)
+    run = {}
+    for part in glob.glob(os.path.join(out, "test.*.trec")):
+        run.update(load_from_trec(part))
+    ev = pytrec_eval.RelevanceEvaluator(qrels, {"ndcg_cut.10", "recall.10"}).evaluate(run)
+    lines = []
+    for measure in sorted(sorted(ev.items())[-1][1].keys()):
+        lines.append("{:25s}{:8s}{:.4f}".format(measure, "all", pytrec_eval.compute_aggregated_measure(measure, [m[measure] for m in ev.values()])))
+    lines.append(f"MRR@10: {eval_mrr(qrels, run, 10)['all']}")
+    assert lines == [str(x) for x in g["lines"]], (lines, g["lines"])
+    assert lines[1] + "\n" == str(g["log"])
+
+
 def _assert_ids_equal_fp64(ids, sc, C, Q, k):
     """ids == the fp64 brute force's, except where two fp64 scores are closer than fp32 summation noise."""
     ref = Q.astype(np.float64) @ C.astype(np.float64).T
@@ -531,7 +570,7 @@ def test_sharded_search_over_rccl_world_of_one(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(NCCL_WORKER)
     env = dict(os.environ, VR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0", VR_OUT=str(tmp_path))
+               HSA_ENABLE_IPC_MODE_LEGACY="0", VR_OUT=str(tmp_path), VISRAG_SHARDED_RETRIEVE="force")   # a world of one skips the transport unless forced
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout
     assert "rank 0 ok all_gathers 3" in p.stdout, p.stdout          # sharded_search + the two corpus-sharded retrieves

@@ -33,7 +33,7 @@ import numpy as np
 import torch
 
 from .engine import HipIndex, topk_merge_keys
-from .utils import list_shards, read_shard
+from .utils import list_shards, read_shard, shard_rank
 
 logger = logging.getLogger(__name__)
 
@@ -75,9 +75,7 @@ def _load_queries(args, rank="own") -> Tuple[np.ndarray, List[str], List[bool]]:
     return np.concatenate(reps), ids, mine
 
 
-def _shard_rank(path: str) -> int:
-    """embeddings.corpus.rank.{r}[.{lo}-{hi}] -> r"""
-    return int(os.path.basename(path).split(".")[3])
+_shard_rank = shard_rank
 
 
 def _sharded_requested(args, sharded: Optional[bool]) -> bool:
@@ -85,8 +83,17 @@ def _sharded_requested(args, sharded: Optional[bool]) -> bool:
         sharded = getattr(args, "sharded_corpus", None)
     if sharded is None:
         sharded = os.environ.get("VISRAG_SHARDED_RETRIEVE", "0") not in ("", "0")
+    return bool(sharded) and _collective_wanted()
+
+
+def _collective_wanted(group=None) -> bool:
+    """A process group of two or more ranks exchanges; a group of ONE rank returns its own result without touching the
+    backend (a single-rank run that happens to have initialised torch.distributed needs no working all-gather) unless
+    VISRAG_SHARDED_RETRIEVE=force asks for the transport anyway (the one-GPU RCCL test)."""
     dist = torch.distributed
-    return bool(sharded) and dist.is_available() and dist.is_initialized()       # (a world of one too: the same code, one rank)
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("VISRAG_SHARDED_RETRIEVE", "") == "force"
 
 
 def distributed_parallel_retrieve(args, topk: int, global_topk: bool = False, sharded: Optional[bool] = None,
@@ -264,10 +271,8 @@ def sharded_search(index, queries, k: int, id_offset: int = 0, group=None,
     if not isinstance(keys, torch.Tensor):
         keys = torch.from_numpy(np.ascontiguousarray(keys))
     merge_fn = merge_keys or topk_merge_keys
-    dist = torch.distributed
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _collective_wanted(group):
         return merge_fn(keys.view((1,) + tuple(keys.shape)))
-    # (an initialised group of ONE rank takes the collective too: the transport runs wherever a group exists)
     return merge_fn(exchange_keys(keys, group))                              # the one collective of the path
 
 

@@ -188,6 +188,47 @@ def synth_pages(n: int, size: int = 448, seed: int = 0, first: int = 0):
     return pages
 
 
+def synth_deck_pages(n_decks: int, per_deck: int = 10, size: int = 448, seed: int = 0, first_deck: int = 0,
+                     slide_bars: int = 3):
+    """`n_decks * per_deck` pages shaped like a slide deck embedded page after page: the slides of a deck share the
+    template (colour mosaic + the template's bars, keyed by the deck id) and differ in `slide_bars` text-like bars of
+    their own and the pixel noise (keyed by (deck, slide)).  Page order: deck-major.  Integer-hash arithmetic only, like
+    `synth_pages`.  Used by the config1sep parity fixture: a query's scores over a deck are near-ties, the decks are as
+    far apart as unrelated pages, so the top-`per_deck` cut of a ranking falls BETWEEN decks."""
+    import numpy as np
+    pages = np.empty((n_decks * per_deck, size, size, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size]
+    with np.errstate(over="ignore"):
+        for d in range(n_decks):
+            did = np.uint64((first_deck + d) * 1000003 + seed * 7919 + 900000017)
+
+            def h(i, salt, pid=did):
+                return _np_mix64(np.asarray(i, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+                                 + pid * np.uint64(0xD1B54A32D192ED03) + np.uint64(salt))
+            cell = 16 + int(h(0, 1) % np.uint64(5)) * 16
+            cid = (yy // cell) * 64 + (xx // cell)
+            base = np.empty((size, size, 3), dtype=np.int32)
+            for c in range(3):
+                base[..., c] = 150 + (h(cid, 10 + c) % np.uint64(100)).astype(np.int32)
+
+            def bars(img, n, pid, salt0):
+                for b in range(n):
+                    y0 = int(h(b, salt0 + 3, pid) % np.uint64(size - 8)); hh = 3 + int(h(b, salt0 + 4, pid) % np.uint64(7))
+                    x0 = int(h(b, salt0 + 5, pid) % np.uint64(size - 40))
+                    ww = 20 + int(h(b, salt0 + 6, pid) % np.uint64(size - x0 - 20))
+                    dark = 1 + int(h(b, salt0 + 7, pid) % np.uint64(7))
+                    img[y0:y0 + hh, x0:x0 + ww, :] = img[y0:y0 + hh, x0:x0 + ww, :] * dark // 16
+            bars(base, 5 + int(h(0, 2) % np.uint64(36)), did, 0)
+            for j in range(per_deck):
+                sid = np.uint64(int(did) * 64 + j + 1)
+                img = base.copy()
+                bars(img, slide_bars, sid, 100)
+                noise = (h(yy * size + xx, 8, sid) % np.uint64(15)).astype(np.int32) - 7
+                img += noise[..., None]
+                pages[d * per_deck + j] = np.clip(img, 0, 255).astype(np.uint8)
+    return pages
+
+
 _WORDS = ("revenue table chart figure growth annual report market share total net income "
           "page section summary results method analysis energy policy climate health data "
           "model system network design process quality budget forecast region quarter").split()

@@ -49,35 +49,52 @@ def load_from_trec(input_path: str, as_list: bool = False, max_len_per_q: int = 
     return res
 
 
-def eval_mrr(qrel: Dict[str, Dict[str, int]], run: Dict[str, Dict[str, float]], cutoff: int = None) -> float:
-    """Mean reciprocal rank of the first relevant doc (utils.py:285-308)."""
+def eval_mrr(qrel: Dict[str, Dict[str, int]], run: Dict[str, Dict[str, float]], cutoff: int = None) -> Dict[str, float]:
+    """MRR@cutoff with the reference's contract (utils.py:285-308): a dict holding the reciprocal rank of the first relevant
+    doc of every query of `qrel` that `run` ranks, plus `'all'` = their mean over exactly those queries (driver/eval.py:303
+    reads `eval_mrr(qrels, run, 10)['all']`).  Queries of `run` without a qrel entry do not count; docs are ranked by
+    descending score in the run's own (stable) order for ties, as `list.sort` leaves them there.  A query `run` ranks no
+    doc for scores 0 (the reference reads a stale variable there); no ranked query at all raises ZeroDivisionError like
+    the reference's `mrr /= num_ranked_q`."""
+    results: Dict[str, float] = {}
     total = 0.0
-    for qid, docs in run.items():
-        ranked = sorted(docs.items(), key=lambda kv: kv[1], reverse=True)
-        if cutoff is not None:
-            ranked = ranked[:cutoff]
-        for i, (doc_id, _) in enumerate(ranked):
-            if qid in qrel and qrel[qid].get(doc_id, 0) > 0:
-                total += 1.0 / (i + 1)
-                break
-    return total / max(1, len(run))
-
-
-def ndcg_recall_at_k(qrel: Dict[str, Dict[str, int]], run: Dict[str, Dict[str, float]], k: int = 10):
-    """pytrec_eval-free nDCG@k / Recall@k (eval.py:281-303 uses pytrec_eval's ndcg_cut / recall)."""
-    nd, rc, n = 0.0, 0.0, 0
     for qid, rels in qrel.items():
         if qid not in run:
             continue
-        n += 1
-        ranked = [d for d, _ in sorted(run[qid].items(), key=lambda kv: kv[1], reverse=True)][:k]
-        dcg = sum((2 ** rels.get(d, 0) - 1) / np.log2(i + 2) for i, d in enumerate(ranked))
-        ideal = sorted(rels.values(), reverse=True)[:k]
-        idcg = sum((2 ** r - 1) / np.log2(i + 2) for i, r in enumerate(ideal))
-        nd += dcg / idcg if idcg > 0 else 0.0
-        npos = sum(1 for r in rels.values() if r > 0)
-        rc += sum(1 for d in ranked if rels.get(d, 0) > 0) / npos if npos else 0.0
-    return (nd / n, rc / n) if n else (0.0, 0.0)
+        ranked = sorted(run[qid].items(), key=lambda kv: kv[1], reverse=True)
+        if cutoff is not None:
+            ranked = ranked[:cutoff]
+        rr = 0.0
+        for i, (doc_id, _) in enumerate(ranked):
+            if rels.get(doc_id, 0) > 0:
+                rr = 1.0 / (i + 1)
+                break
+        results[qid] = rr
+        total += rr
+    n = len(results)
+    results["all"] = total / n
+    return results
+
+
+def get_qrels_from_hf_repo(dataset_name: str) -> Dict[str, Dict[str, int]]:
+    """qrels of a HuggingFace dataset repository, `{query-id: {corpus-id: score}}` (utils.py:310-325: the `qrels` config's
+    `train` split).  Host-side data loading, kept so that `driver/eval.py:24` imports all four names from one module."""
+    import datasets
+    qrels: Dict[str, Dict[str, int]] = {}
+    for row in datasets.load_dataset(dataset_name, "qrels")["train"]:
+        qrels.setdefault(row["query-id"], {})[row["corpus-id"]] = row["score"]
+    return qrels
+
+
+def ndcg_recall_at_k(qrel: Dict[str, Dict[str, int]], run: Dict[str, Dict[str, float]], k: int = 10):
+    """nDCG@k / Recall@k as driver/eval.py:281-301 prints them (trec_eval's `ndcg_cut` / `recall` through
+    `visrag_amd.pytrec_eval`: linear gain, ties by descending doc id), averaged over the queries both dicts hold."""
+    from . import pytrec_eval
+    ev = pytrec_eval.RelevanceEvaluator(qrel, {f"ndcg_cut.{k}", f"recall.{k}"}).evaluate(run)
+    if not ev:
+        return 0.0, 0.0
+    return (pytrec_eval.compute_aggregated_measure(f"ndcg_cut_{k}", [m[f"ndcg_cut_{k}"] for m in ev.values()]),
+            pytrec_eval.compute_aggregated_measure(f"recall_{k}", [m[f"recall_{k}"] for m in ev.values()]))
 
 
 # ---- pickle embedding shards: (np.float32[n, D], list[str]) protocol 4 ---------------------
@@ -103,5 +120,12 @@ def list_shards(output_dir: str, dataset_type: str, rank: int = None) -> List[st
     if rank is not None:
         # the reference's glob `rank.{r}*` (dense_retriever.py:40-46) also matches ranks 10 r .. 10 r + 9 of a larger world:
         # keep the files whose rank field IS r
-        files = [f for f in files if os.path.basename(f).split(".")[3] == str(rank)]
+        files = [f for f in files if shard_rank(f) == int(rank)]
     return files
+
+
+def shard_rank(path: str) -> int:
+    """`embeddings.{type}.rank.{r}[.{lo}-{hi}]` -> r: the field behind the LAST `.rank.` (a dataset_type with dots of its own
+    does not shift it)."""
+    tail = os.path.basename(path).rsplit(".rank.", 1)[1]
+    return int(tail.split(".", 1)[0])
