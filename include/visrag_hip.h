@@ -71,8 +71,10 @@ typedef struct vr_config {
                                    * the 1e-3 score bar for ~20-token queries); 0: the bf16 path for everything;
                                    * N > 1: only token-only batches whose longest sequence has <= N tokens (512 = the
                                    * reference's query length): longer text passages stay on the bf16 MFMA attention path.
-                                   * The same text item is therefore embedded at fp32-class precision in a token-only batch
-                                   * and at bf16 precision (inside 1e-3) in a batch that also holds an image. */
+                                   * The route is per vr_encode CALL (a call with image slices runs the bf16 pass for all its
+                                   * items); the host adapter (visrag_amd/modeling.py: encode_prepared) therefore groups the
+                                   * token-only items of a batch into calls of their own, so that an item's embedding does not
+                                   * depend on its batch mates. */
 } vr_config_t;
 
 /* ---- library ------------------------------------------------------------------------ */

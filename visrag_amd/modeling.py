@@ -150,8 +150,25 @@ class DRModelForInference:
         return None, reps
 
     def encode_prepared(self, prepared: List[PreparedItem], enc: Optional[HipEncoder] = None) -> torch.Tensor:
-        """Splits into micro-batches that fit the workspace (tokens / sequences)."""
+        """Splits into micro-batches that fit the workspace (tokens / sequences).
+
+        The precision route is chosen PER ITEM, not per batch: the library runs a micro-batch without image slices through the
+        split-precision decoder pass (fp32-class; include/visrag_hip.h: text_split_precision) and one with slices through the
+        bf16 pass, so token-only items are grouped into micro-batches of their own — a query's embedding no longer depends
+        on whether a page happens to sit in the same call.  Item order of the result = item order of the call."""
         enc = enc or self.encoder
+        text_only = [i for i, it in enumerate(prepared) if not it.slices]
+        if 0 < len(text_only) < len(prepared) and getattr(self.cfg, "text_split_precision", 1):
+            with_img = [i for i, it in enumerate(prepared) if it.slices]
+            parts = [(text_only, self._encode_group([prepared[i] for i in text_only], enc)),
+                     (with_img, self._encode_group([prepared[i] for i in with_img], enc))]
+            out = torch.empty((len(prepared), parts[0][1].shape[1]), dtype=parts[0][1].dtype, device=parts[0][1].device)
+            for idx, reps in parts:
+                out[torch.as_tensor(idx, device=out.device)] = reps
+            return out
+        return self._encode_group(prepared, enc)
+
+    def _encode_group(self, prepared: List[PreparedItem], enc: HipEncoder) -> torch.Tensor:
         outs, cur, tok = [], [], 0
         for it in prepared:
             n = len(it.input_ids)
