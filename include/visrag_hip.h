@@ -125,6 +125,20 @@ int vr_encode(vr_model_t m,
               const int32_t* vision_rows,
               float* out_reps, int32_t out_on_device, void* stream);
 
+/* vr_encode, and ALSO the last hidden states the pooling reads — the HF-style forward of the reference's second caller:
+ * `outputs = model(text=..., image=..., tokenizer=...)` returns `last_hidden_state` [B, L, hidden] + `attention_mask` and the
+ * caller pools them itself (visrag_scripts/demo/visrag_pipeline/utils.py:12-32, demo/retriever/demo.py:14-36;
+ * BaseModelOutputWithAttentionMask, modeling_visrag_ret.py:123-126).
+ *   out_hidden  [B][hidden_len][hidden_size] float32 on the DEVICE: item i's post-norm rows, right-padded with zeros like the
+ *               reference's `pad` (modeling_minicpmv.py:440-479); hidden_len >= the longest item. */
+int vr_encode_hidden(vr_model_t m,
+                     const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
+                     int32_t slices_on_device,
+                     const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
+                     const int32_t* vision_rows,
+                     float* out_reps, int32_t out_on_device,
+                     float* out_hidden, int32_t hidden_len, void* stream);
+
 /* Pooling of the last hidden states (DRModel.encode, dense_retrieval_model.py:172-220), applied after the
  * final RMSNorm and followed by the L2 normalisation (:222-223).  VisRAG-Ret's published setting is wmean
  * (the default).  The reference's drop_wmean / drop_mean / lasttoken_simcse apply dropout in training mode

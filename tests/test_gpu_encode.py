@@ -72,6 +72,59 @@ def test_tiny_encode_vs_reference_golden(tiny_model, golden_dir):
     np.testing.assert_allclose(q @ p.T, g["q_reps"] @ g["p_reps"].T, atol=2.5 * TOL)
 
 
+def test_hf_style_forward_of_the_demo_caller(tiny_model):
+    """the demo scripts call the bare model, `outputs = model(text=, image=, tokenizer=)`, and pool
+    `outputs.last_hidden_state` with `outputs.attention_mask` themselves (visrag_scripts/demo/visrag_pipeline/utils.py:4-32).
+    `DRModelForInference.lm_q` offers that call (vr_encode_hidden): the padded hidden states against the oracle's, the mask
+    against the token counts, and the demo's own pooling statements applied to them against the library's pooled embeddings."""
+    import torch.nn.functional as F
+    cfg, enc, model = tiny_model
+    tok = StandInTokenizer(cfg.vocab_size)
+    pages = _tiny_pages(cfg)
+
+    def demo_encode(m, tokenizer, text_or_image_list):                      # the caller's code, statement for statement
+        if isinstance(text_or_image_list[0], str):
+            inputs = {"text": text_or_image_list, "image": [None] * len(text_or_image_list), "tokenizer": tokenizer}
+        else:
+            inputs = {"text": [""] * len(text_or_image_list), "image": text_or_image_list, "tokenizer": tokenizer}
+        outputs = m(**inputs)
+        attention_mask = outputs.attention_mask
+        hidden = outputs.last_hidden_state
+        attention_mask_ = attention_mask * attention_mask.cumsum(dim=1)
+        s_ = torch.sum(hidden * attention_mask_.unsqueeze(-1).float(), dim=1)
+        d_ = attention_mask_.sum(dim=1, keepdim=True).float()
+        return F.normalize(s_ / d_, p=2, dim=1).detach().cpu().numpy(), outputs
+
+    lm = model.lm_q
+    imgs = [_pil(p) for p in pages]
+    reps, out = demo_encode(lm, tok, imgs)
+    items = prepare_batch([""] * len(imgs), imgs, tok, cfg, 2048)
+    lens = [len(it.input_ids) for it in items]
+    assert tuple(out.last_hidden_state.shape) == (len(imgs), max(lens), cfg.hidden_size) and out.last_hidden_state.is_cuda
+    assert out.attention_mask.dtype == torch.int8 and out.attention_mask.sum(1).tolist() == lens
+    own = model.encode_prepared(items).cpu().numpy()
+    assert ((reps * own).sum(1)).min() > 1 - 1e-6                            # the caller's pooling == the fused pool kernel
+    taps = {}
+    ref = O.encode(synth_state_dict(cfg, 0), cfg, [it.input_ids for it in items], [it.image_bound for it in items],
+                   [it.slices for it in items], taps=taps).numpy()
+    assert ((reps * ref).sum(1)).min() > 1 - TOL
+    h, hr = out.last_hidden_state.cpu().numpy(), taps["last_hidden"].numpy()
+    for i, n in enumerate(lens):
+        assert np.abs(h[i, :n] - hr[i, :n]).max() < 3e-2 * np.abs(hr[i, :n]).max(), i
+        assert not h[i, n:].any()                                             # right padding: zeros
+    # text: five queries, one of them next to nothing else; and a mixed call (a None image among pages)
+    qs = [QUERY_PREFIX + t for t in synth_queries(5, seed=1)]
+    qreps, qout = demo_encode(lm, tok, qs)
+    qitems = prepare_batch(qs, [None] * 5, tok, cfg, 2048)
+    assert ((qreps * model.encode_prepared(qitems).cpu().numpy()).sum(1)).min() > 1 - 1e-6
+    mixed = lm(text=[qs[0], "", qs[1]], image=[None, imgs[4], None], tokenizer=tok)
+    assert mixed.attention_mask.sum(1).tolist() == [len(qitems[0].input_ids), lens[4], len(qitems[1].input_ids)]
+    assert torch.equal(mixed.last_hidden_state[0, :len(qitems[0].input_ids)], qout.last_hidden_state[0, :len(qitems[0].input_ids)]) or \
+        torch.allclose(mixed.last_hidden_state[0, :len(qitems[0].input_ids)], qout.last_hidden_state[0, :len(qitems[0].input_ids)], atol=1e-4)
+    with pytest.raises(ValueError):
+        lm(text=["a"], image=[None, None], tokenizer=tok)
+
+
 def test_tiny_encode_vs_oracle_batch_invariance(tiny_model):
     """Same pages in different batch compositions / orders give the same embeddings, and they
     match the CPU oracle run here on the same inputs."""

@@ -64,6 +64,8 @@ SIGNATURES = {
     "vr_model_clone": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "vr_encode": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i32), _i32, _i32, C.POINTER(_i32),
                             C.POINTER(_i32), _i32, C.POINTER(_i32), _vp, _i32, _vp]),
+    "vr_encode_hidden": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i32), _i32, _i32, C.POINTER(_i32),
+                                   C.POINTER(_i32), _i32, C.POINTER(_i32), _vp, _i32, _vp, _i32, _vp]),
     "vr_model_tap": (C.c_int, [_vp, C.c_char_p, _vp, _i64, _i64]),
     "vr_model_set_taps": (C.c_int, [_vp, _i32]),
     "vr_model_set_pooling": (C.c_int, [_vp, _i32]),

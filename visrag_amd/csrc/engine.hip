@@ -76,6 +76,7 @@ struct vr_model_s {
     DevBuf w_cu, w_ids, w_seq, w_pos, w_rowmap, w_imgptr, w_pix, w_out;
     DevBuf w_hp_hi, w_hp_planes, w_hp_qkv, w_hp_att, w_hp_gu, w_seqof;   // split-precision text path (hp_text.hip)
     DevBuf w_hp_part;                                                 // its split-K planes for short batches (grown on demand)
+    DevBuf w_hidden;                                                  // vr_encode_hidden: packed post-norm rows when the resampler's scratch is too small (grown on demand)
     std::map<std::string, Tap> taps;
     // HIP-event profiling of kernel classes (bench.py roofline): pairs recorded on the launch
     // stream, elapsed times summed lazily in vr_model_get_profile
@@ -188,7 +189,7 @@ extern "C" int vr_model_destroy(vr_model_t m) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp,
                       &m->w_kv32, &m->w_xkv, &m->w_KV, &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv,
                       &m->w_datt, &m->w_dact, &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr,
-                      &m->w_pix, &m->w_out, &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part})
+                      &m->w_pix, &m->w_out, &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part, &m->w_hidden})
         b->free();
     delete m;
     return VR_OK;
@@ -902,7 +903,8 @@ static int run_decoder_hp(vr_model_s* m, int T, int B, int max_len, hipStream_t 
 
 static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
                        int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
-                       const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream);
+                       const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream,
+                       float* out_hidden = nullptr, int32_t hidden_len = 0);
 
 extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
                          int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
@@ -922,9 +924,29 @@ extern "C" int vr_encode(vr_model_t m, const uint8_t* const* slices, const int32
     return rc;
 }
 
+// The HF-style forward of the second caller (visrag_scripts/demo/visrag_pipeline/utils.py:12-32 pools `last_hidden_state` itself):
+// the same pass, and the post-norm hidden states as a right-padded [B][hidden_len][hidden_size] fp32 device tensor.
+extern "C" int vr_encode_hidden(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
+                                int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
+                                const int32_t* vision_rows, float* out_reps, int32_t out_on_device, float* out_hidden,
+                                int32_t hidden_len, void* stream) {
+    if (!m) return fail(VR_ERR_INVALID, "NULL model");
+    if (!out_hidden || hidden_len <= 0) return fail(VR_ERR_INVALID, "out_hidden is NULL or hidden_len <= 0");
+    m->arena_open = false;
+    const int rc = encode_impl(m, slices, slice_hw, n_slices, slices_on_device, input_ids, seq_offsets, B, vision_rows,
+                               out_reps, out_on_device, stream, out_hidden, hidden_len);
+    if (m->arena_open && m->arena_ev) {
+        if (hipEventRecord(m->arena_ev, (hipStream_t)stream) == hipSuccess) m->arena_pending = true;
+        else (void)hipStreamSynchronize((hipStream_t)stream);
+    }
+    m->arena_open = false;
+    return rc;
+}
+
 static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t* slice_hw, int32_t n_slices,
                        int32_t slices_on_device, const int32_t* input_ids, const int32_t* seq_offsets, int32_t B,
-                       const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream) {
+                       const int32_t* vision_rows, float* out_reps, int32_t out_on_device, void* stream,
+                       float* out_hidden, int32_t hidden_len) {
     if (!m->finalized) return fail(VR_ERR_STATE, "vr_model_finalize() has not succeeded");
     if (B <= 0 || !input_ids || !seq_offsets || !out_reps) return fail(VR_ERR_INVALID, "empty batch or NULL argument");
     if (n_slices > 0 && (!slices || !slice_hw || !vision_rows)) return fail(VR_ERR_INVALID, "NULL slice arguments");
@@ -1143,9 +1165,22 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
     // ---- K19+K20: final norm + wmean pool + L2 normalise
     float* tap_hidden = nullptr;   // scratch f32 [T][E] for the post-norm hidden states
     if (m->taps_on && (size_t)T * E * 4 <= m->w_kv32.bytes) tap_hidden = m->w_kv32.as<float>();
+    if (out_hidden) {              // vr_encode_hidden: the packed rows first (the resampler's scratch when it is large enough)
+        if (max_len > hidden_len) return fail(VR_ERR_INVALID, "hidden_len=%d is shorter than the longest sequence (%d)", hidden_len, max_len);
+        if (!tap_hidden) {
+            if ((size_t)T * E * 4 <= m->w_kv32.bytes) tap_hidden = m->w_kv32.as<float>();
+            else { VRCHK(m->w_hidden.reserve((size_t)T * E * 4)); tap_hidden = m->w_hidden.as<float>(); }
+        }
+    }
     float* dst = out_on_device ? out_reps : m->w_out.as<float>();
     HIPCHK(launch_pool(h, seq, B, E, m->final_norm.v.as<float>(), c.rms_norm_eps, dst, tap_hidden, s, m->pool_mode));
-    if (tap_hidden) VRCHK(tap_store(m, "last_hidden", tap_hidden, T, E, E, false, s));
+    if (tap_hidden && m->taps_on) VRCHK(tap_store(m, "last_hidden", tap_hidden, T, E, E, false, s));
+    if (out_hidden) {              // right padding (modeling_minicpmv.py:440-479 `pad`): item i -> rows [i * hidden_len, + len_i), zeros behind
+        HIPCHK(hipMemsetAsync(out_hidden, 0, (size_t)B * hidden_len * E * 4, s));
+        for (int i = 0; i < B; ++i)
+            HIPCHK(hipMemcpyAsync(out_hidden + (size_t)i * hidden_len * E, tap_hidden + (size_t)seq_offsets[i] * E,
+                                  (size_t)(seq_offsets[i + 1] - seq_offsets[i]) * E * 4, hipMemcpyDeviceToDevice, s));
+    }
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out_reps, dst, (size_t)B * E * 4, hipMemcpyDeviceToHost, s));
     if (!out_on_device || (n_slices > 0 && !slices_on_device)) HIPCHK(hipStreamSynchronize(s));   // host buffers consumed
     return VR_OK;
@@ -1164,7 +1199,7 @@ extern "C" int vr_model_clone(vr_model_t src, vr_model_t* out) {
     for (DevBuf* b : {&m->w_hvit, &m->w_xn, &m->w_qkv, &m->w_att, &m->w_mlp, &m->w_kv32, &m->w_xkv, &m->w_KV,
                       &m->w_ratt, &m->w_rout, &m->w_rln, &m->w_h, &m->w_dxn, &m->w_part, &m->w_dqkv, &m->w_datt, &m->w_dact,
                       &m->w_cu, &m->w_ids, &m->w_seq, &m->w_pos, &m->w_rowmap, &m->w_imgptr, &m->w_pix, &m->w_out,
-                      &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part}) {
+                      &m->w_hp_hi, &m->w_hp_planes, &m->w_hp_qkv, &m->w_hp_att, &m->w_hp_gu, &m->w_seqof, &m->w_hp_part, &m->w_hidden}) {
         b->free();                                 // (a non-owning alias after the copy: just forget it)
     }
     m->grids.clear();                              // (entries alias the source's tables; the clone builds its own)

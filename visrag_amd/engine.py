@@ -134,10 +134,12 @@ class HipEncoder:
 
     # ---- encode ---------------------------------------------------------------------------
     def encode_items(self, items: Sequence[PreparedItem], device_slices: Optional[List[torch.Tensor]] = None,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, hidden_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """items -> unit-norm embeddings [B, hidden] float32 on the device.
         `device_slices`: optional uint8 HWC cuda tensors replacing the host slices of the items
-        (same order: item 0's slices first, ...)."""
+        (same order: item 0's slices first, ...).
+        `hidden_out`: optional float32 cuda tensor [B, L, hidden] (L >= the longest item) that receives the last hidden
+        states, right-padded with zeros (vr_encode_hidden: the HF-style forward's `last_hidden_state`)."""
         cfg = self.cfg
         B = len(items)
         if B == 0:
@@ -185,6 +187,16 @@ class HipEncoder:
             ptrs, hw_arr, vr_p = None, None, None
         if out is None:
             out = torch.empty((B, cfg.hidden_size), dtype=torch.float32, device=f"cuda:{self.device}")
+        if hidden_out is not None:
+            if not (hidden_out.is_cuda and hidden_out.dtype == torch.float32 and hidden_out.is_contiguous() and hidden_out.dim() == 3
+                    and hidden_out.shape[0] == B and hidden_out.shape[2] == cfg.hidden_size):
+                raise ValueError("hidden_out must be a contiguous float32 cuda tensor [B, L, hidden_size]")
+            _lib.check(self.lib.vr_encode_hidden(
+                self._h, ptrs, hw_arr, n_slices, on_dev,
+                ids.ctypes.data_as(C.POINTER(C.c_int32)), seq.ctypes.data_as(C.POINTER(C.c_int32)), B,
+                vr_p, C.c_void_p(out.data_ptr()), 1, C.c_void_p(hidden_out.data_ptr()), int(hidden_out.shape[1]),
+                C.c_void_p(_stream_ptr(self.device))), "vr_encode_hidden")
+            return out
         _lib.check(self.lib.vr_encode(
             self._h, ptrs, hw_arr, n_slices, on_dev,
             ids.ctypes.data_as(C.POINTER(C.c_int32)), seq.ctypes.data_as(C.POINTER(C.c_int32)), B,

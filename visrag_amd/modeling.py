@@ -117,6 +117,13 @@ class DRModelForInference:
     def device(self) -> torch.device:
         return torch.device(f"cuda:{self.encoder.device}")
 
+    @property
+    def lm_q(self) -> "VisRAGRet":
+        """The underlying model with its HF-style forward (dense_retrieval_model.py:67-68: `lm_q` / `lm_p`, tied)."""
+        return VisRAGRet(self)
+
+    lm_p = lm_q
+
     # ---- reference API ----------------------------------------------------------------------
     def encode(self, items: Optional[Dict], is_query: bool = False, tokenizer=None,
                max_inp_length: int = 2048, **_):
@@ -196,6 +203,84 @@ class DRModelForInference:
         return DROutput(q_reps=q_reps, p_reps=p_reps)
 
     __call__ = forward
+
+
+@dataclass
+class BaseModelOutputWithAttentionMask:
+    """modeling_visrag_ret.py:24-27"""
+    last_hidden_state: Optional[torch.Tensor] = None
+    attention_mask: Optional[torch.Tensor] = None
+
+
+class VisRAGRet:
+    """The HF-style forward of the reference's SECOND caller: the demo scripts hold the bare
+    `VisRAG_Ret` model and pool its output themselves,
+
+        outputs = model(text=[...], image=[PIL | None, ...], tokenizer=tokenizer)      # demo/visrag_pipeline/utils.py:12-32
+        reps = weighted_mean_pooling(outputs.last_hidden_state, outputs.attention_mask)
+
+    (modeling_visrag_ret.py:86-126).  Same call here: `last_hidden_state` [B, L, hidden] float32 on the device, right-padded
+    with zeros, `attention_mask` [B, L] int8 (modeling_minicpmv.py:464), both from ONE pass of the library
+    (vr_encode_hidden).  `DRModelForInference.lm_q` / `.lm_p` are this object, like the reference's attributes."""
+
+    def __init__(self, owner: "DRModelForInference"):
+        self._owner = owner
+        self.config = owner.cfg
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kw) -> "VisRAGRet":
+        return DRModelForInference.build(types_namespace(model_name_or_path=path), **kw).lm_q
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        self._owner.to(*a, **k)
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self._owner.device
+
+    def forward(self, text: List[str], image: List, tokenizer, max_inp_length: int = 2048, **_) -> BaseModelOutputWithAttentionMask:
+        if len(text) != len(image):
+            raise ValueError("text and image lists must have the same length")
+        own = self._owner
+        enc = own.encoder
+        prepared = prepare_batch(list(text), list(image), tokenizer, own.cfg, max_inp_length)
+        L = max(len(it.input_ids) for it in prepared)
+        dev = torch.device(f"cuda:{enc.device}")
+        hidden = torch.empty((len(prepared), L, own.cfg.hidden_size), dtype=torch.float32, device=dev)
+        mask = torch.zeros((len(prepared), L), dtype=torch.int8)
+        for i, it in enumerate(prepared):
+            mask[i, :len(it.input_ids)] = 1
+        # one library call per precision route and workspace-sized micro-batch, each writing its rows of `hidden`
+        text_only = [i for i, it in enumerate(prepared) if not it.slices]
+        with_img = [i for i, it in enumerate(prepared) if it.slices]
+        split = bool(text_only) and bool(with_img) and bool(getattr(own.cfg, "text_split_precision", 1))
+        for group in ([text_only, with_img] if split else [list(range(len(prepared)))]):
+            cur, tok = [], 0
+            for i in group + [None]:
+                n = 0 if i is None else len(prepared[i].input_ids)
+                if cur and (i is None or tok + n > enc.max_tokens or len(cur) >= enc.max_seqs):
+                    contiguous = cur == list(range(cur[0], cur[0] + len(cur)))
+                    part = hidden[cur[0]:cur[0] + len(cur)] if contiguous else torch.empty((len(cur), L, hidden.shape[2]), dtype=torch.float32, device=dev)
+                    enc.encode_items([prepared[j] for j in cur], hidden_out=part)
+                    if not contiguous:
+                        hidden[torch.as_tensor(cur, device=dev)] = part
+                    cur, tok = [], 0
+                if i is not None:
+                    if n > enc.max_tokens:
+                        raise ValueError(f"sequence of {n} tokens exceeds the encoder workspace (max_tokens={enc.max_tokens})")
+                    cur.append(i); tok += n
+        return BaseModelOutputWithAttentionMask(last_hidden_state=hidden, attention_mask=mask.to(dev))
+
+    __call__ = forward
+
+
+def types_namespace(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
 
 
 def default_device() -> int:
