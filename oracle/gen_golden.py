@@ -216,13 +216,13 @@ SEP_DECKS, SEP_PER_DECK, SEP_LOOSE = 51, 10, 2
 
 
 def sep_pages(lo, n):
-    """Pages lo .. lo+n-1 of the config1sep corpus: 51 decks x 10 slides (synth_deck_pages, one slide-specific bar), then
+    """Pages lo .. lo+n-1 of the config1sep corpus: 51 decks x 10 slides (synth_deck_pages: a slide differs from its deck's template by ONE small mark), then
     two loose pages (synth_pages 0, 1)."""
     nd = SEP_DECKS * SEP_PER_DECK
     out = []
     for i in range(lo, lo + n):
         if i < nd:
-            out.append(synth_deck_pages(1, SEP_PER_DECK, size=448, seed=0, first_deck=i // SEP_PER_DECK, slide_bars=1)[i % SEP_PER_DECK])
+            out.append(synth_deck_pages(1, SEP_PER_DECK, size=448, seed=0, first_deck=i // SEP_PER_DECK, slide_bars=1, slide_noise=False)[i % SEP_PER_DECK])
         else:
             out.append(synth_pages(1, size=448, seed=0, first=i - nd)[0])
     return np.stack(out)
@@ -240,7 +240,7 @@ def config1sep(n_queries=1022, bs=16, k=10, state="/tmp/config1sep_state.npz"):
     between its best and second-best deck.  Same chain as config1xl: the reference's DRModelForInference (CPU fp32,
     batches of 16) and its distributed_parallel_retrieve top-10 over four pickle shards."""
     _config1_chain("config1sep_full.npz", sep_pages, SEP_DECKS * SEP_PER_DECK + SEP_LOOSE, n_queries, 1, bs, k, state,
-                   extra=dict(n_decks=SEP_DECKS, per_deck=SEP_PER_DECK, n_loose=SEP_LOOSE, slide_bars=1))
+                   extra=dict(n_decks=SEP_DECKS, per_deck=SEP_PER_DECK, n_loose=SEP_LOOSE, slide_bars=1, slide_noise=0))
 
 
 def _config1_chain(out_name, page_fn, n_pages, n_queries, query_seed, bs, k, state, extra):

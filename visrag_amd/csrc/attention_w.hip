@@ -725,8 +725,13 @@ bool attention72w_ok(const AttnArgs& a) {
     if (a.lse) return false;
 #endif
     if (a.ldk != a.ldv || (a.ldk & 7) || (a.ldq & 7) || (a.ldo & 3)) return false;
+    // k and v must be columns of the SAME rows (the qkv GEMM's output): the kernel reads both through one descriptor over
+    // [k, v + len), K-tile rows past kv_len and the 16-byte pad chunk behind a head's 144 bytes come from whatever lies in
+    // between — inside one row buffer that is finite model data (a pad chunk of garbage bits would reach the tail MFMA as
+    // 0 * NaN); separate allocations would be read out of bounds.  Anything else runs on attention.hip.
     const long long delta = (const char*)a.v - (const char*)a.k;
-    if (delta < 0 || delta > (1ll << 30)) return false;
+    if (delta <= 0 || delta >= (long long)a.ldk * 2) return false;
+    if ((long long)a.heads * AW_HD * 2 > delta) return false;               // (the k columns end before the v columns begin)
     if (a.max_q < 192) return false;
     // 256-row query tiles: worth it when they are (nearly) full — a 1026-row image would waste a fifth of the grid
     const int full = (a.max_q + AW_QT - 1) / AW_QT * AW_QT;
@@ -764,12 +769,14 @@ hipError_t launch_attention72w(const AttnArgs& a_in, hipStream_t s) {
     static unsigned long long attr = 0;
     set_max_dynamic_lds((const void*)k, AW_SMEM_ALL, attr);
     // persistent: one workgroup per CU (120 KiB of LDS each) walking the units
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
+    static int cu_of[64] = {0};                                             // per device id
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cu_of[dev]) {
+        hipDeviceProp_t prop;
+        cu_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int n_cu = cu_of[dev];
     const int units = a.B * a.heads * q_tiles;
     hipLaunchKernelGGL(k, dim3(units < n_cu ? units : n_cu), dim3(64 * NW), AW_SMEM_ALL, s, a);
     return hipGetLastError();

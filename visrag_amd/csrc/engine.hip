@@ -699,8 +699,10 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
     if (first_group) VRCHK(tap_store(m, "vit_embed", h, N, D, Dp, false, s));
     const int ldqkv = pad128(3 * D);
     // (the plain bf16 epilogue scales whole 64-column blocks: the q section must end on one, as 16 x 72 does)
+    // NOTE for any other reader of w_qkv: its q columns hold q * head_dim^-0.5 * log2(e), not q (AttnArgs::q_prescaled)
+    const int vit_hd = c.vit_dim / c.vit_heads;                          // (72: checked at vr_model_create)
     const int vit_qscale_n = D % 64 == 0 ? D : 0;
-    const float vit_qscale = (1.0f / sqrtf(72.0f)) * 1.44269504088896340736f;
+    const float vit_qscale = (1.0f / sqrtf((float)vit_hd)) * 1.44269504088896340736f;
     for (int l = 0; l < c.vit_depth; ++l) {
         const VitBlock& b = m->blocks[l];
         HIPCHK(launch_layernorm(h, M, D, Dp, b.n1w.v.as<float>(), b.n1b.v.as<float>(), c.vit_ln_eps, m->w_xn.p, Dp, s));
@@ -719,7 +721,7 @@ static int run_vision_group(vr_model_s* m, const uint8_t* const* dev_imgs_hostar
             a.k = (const char*)m->w_qkv.p + (size_t)D * 2; a.ldk = ldqkv;
             a.v = (const char*)m->w_qkv.p + (size_t)2 * D * 2; a.ldv = ldqkv;
             a.out = m->w_att.p; a.ldo = Dp; a.cu_q = cu_tok; a.cu_kv = cu_tok; a.B = n; a.heads = c.vit_heads;
-            a.head_dim = 72; a.max_q = N; a.causal = 0; a.q_shared = 0; a.scale = 1.0f / sqrtf(72.0f); a.q_prescaled = vit_qscale_n > 0;
+            a.head_dim = vit_hd; a.max_q = N; a.causal = 0; a.q_shared = 0; a.scale = 1.0f / sqrtf((float)vit_hd); a.q_prescaled = vit_qscale_n > 0;
             VRCHK(prof_begin(m, VR_PROF_VIT_ATTN, s));
             HIPCHK(launch_attention(a, s));
             VRCHK(prof_end(m, VR_PROF_VIT_ATTN, 4.0 * n * (double)N * N * D, s));

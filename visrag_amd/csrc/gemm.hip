@@ -142,6 +142,8 @@ static hipError_t launch_epi(const GemmArgs& a_in, int variant, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
+    // column scaling exists in the bf16-output epilogues only, on whole 64-column blocks (the tile forms test the block start)
+    if (a.col_scale_n != 0 && (epi != EPI_BF16 || a.col_scale_n < 0 || a.col_scale_n % 64 != 0)) return hipErrorInvalidValue;
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_256W) return launch_gemm256w(a, epi, s);
     if (variant == GEMM_VARIANT_192W) return launch_gemm192w(a, epi, s);

@@ -108,7 +108,10 @@ static hipError_t launch_w(const GemmArgs& a, hipStream_t s) {
 // the LDS-DMA addresses whole matrices through 32-bit offsets: both operands (rows padded to the tile) below 2 GiB
 bool gemm256w_fits(const GemmArgs& a, int bn) {
     const size_t tm = (a.M + G256_BM - 1) / G256_BM, tn = (a.N + bn - 1) / bn;
-    return tm * G256_BM * (size_t)a.lda * 2 < (1ull << 31) && tn * bn * (size_t)a.ldw * 2 < (1ull << 31);
+    // ... and the buffer-descriptor epilogues count a tile's output rows (and the row-bias table) in 32-bit byte offsets whose
+    // out-of-range marker is +2^31: 256 rows of fp32 at pitch ldo must stay below that
+    return tm * G256_BM * (size_t)a.lda * 2 < (1ull << 31) && tn * bn * (size_t)a.ldw * 2 < (1ull << 31) &&
+           (size_t)G256_BM * (size_t)a.ldo * 4 < (1ull << 31) && (!a.rowbias || (size_t)G256_BM * (size_t)a.rowbias_ld * 4 < (1ull << 31));
 }
 
 hipError_t launch_gemm256w(const GemmArgs& a, int epi, hipStream_t s) {

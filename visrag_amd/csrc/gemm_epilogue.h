@@ -123,7 +123,7 @@ __device__ __forceinline__ void gemm_epilogue_row(f32x4 (&acc)[NF], const GemmAr
             if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
             if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
                 if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
-                if constexpr (EPI == EPI_BF16) { if (nb < p.col_scale_n) v *= p.col_scale; }       // (GemmArgs::col_scale)
+                if constexpr (EPI == EPI_BF16) { if (n < p.col_scale_n) v *= p.col_scale; }        // (GemmArgs::col_scale: per column)
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_lds_general(f32x4 (&acc)[MI][
                     if (rb && n < p.rowbias_cols) v += *reinterpret_cast<const f32x4*>(rb + n);
                 }
                 if constexpr (EPI == EPI_GELU) v = gelu_erf4(v);
-                if constexpr (EPI == EPI_BF16) { if (nb < p.col_scale_n) v *= p.col_scale; }       // (GemmArgs::col_scale)
+                if constexpr (EPI == EPI_BF16) { if (n < p.col_scale_n) v *= p.col_scale; }        // (GemmArgs::col_scale: per column)
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);

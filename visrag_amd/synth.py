@@ -189,10 +189,10 @@ def synth_pages(n: int, size: int = 448, seed: int = 0, first: int = 0):
 
 
 def synth_deck_pages(n_decks: int, per_deck: int = 10, size: int = 448, seed: int = 0, first_deck: int = 0,
-                     slide_bars: int = 3):
+                     slide_bars: int = 3, slide_noise: bool = True):
     """`n_decks * per_deck` pages shaped like a slide deck embedded page after page: the slides of a deck share the
     template (colour mosaic + the template's bars, keyed by the deck id) and differ in `slide_bars` text-like bars of
-    their own and the pixel noise (keyed by (deck, slide)).  Page order: deck-major.  Integer-hash arithmetic only, like
+    their own (small: page-number-sized marks) and, with `slide_noise`, the pixel noise (keyed by (deck, slide); else by the deck).  Page order: deck-major.  Integer-hash arithmetic only, like
     `synth_pages`.  Used by the config1sep parity fixture: a query's scores over a deck are near-ties, the decks are as
     far apart as unrelated pages, so the top-`per_deck` cut of a ranking falls BETWEEN decks."""
     import numpy as np
@@ -211,19 +211,19 @@ def synth_deck_pages(n_decks: int, per_deck: int = 10, size: int = 448, seed: in
             for c in range(3):
                 base[..., c] = 150 + (h(cid, 10 + c) % np.uint64(100)).astype(np.int32)
 
-            def bars(img, n, pid, salt0):
+            def bars(img, n, pid, salt0, small=False):
                 for b in range(n):
-                    y0 = int(h(b, salt0 + 3, pid) % np.uint64(size - 8)); hh = 3 + int(h(b, salt0 + 4, pid) % np.uint64(7))
+                    y0 = int(h(b, salt0 + 3, pid) % np.uint64(size - 8)); hh = 3 + int(h(b, salt0 + 4, pid) % np.uint64(3 if small else 7))
                     x0 = int(h(b, salt0 + 5, pid) % np.uint64(size - 40))
-                    ww = 20 + int(h(b, salt0 + 6, pid) % np.uint64(size - x0 - 20))
-                    dark = 1 + int(h(b, salt0 + 7, pid) % np.uint64(7))
+                    ww = 20 + int(h(b, salt0 + 6, pid) % np.uint64(29 if small else size - x0 - 20))
+                    dark = (10 if small else 1) + int(h(b, salt0 + 7, pid) % np.uint64(4 if small else 7))
                     img[y0:y0 + hh, x0:x0 + ww, :] = img[y0:y0 + hh, x0:x0 + ww, :] * dark // 16
             bars(base, 5 + int(h(0, 2) % np.uint64(36)), did, 0)
             for j in range(per_deck):
                 sid = np.uint64(int(did) * 64 + j + 1)
                 img = base.copy()
-                bars(img, slide_bars, sid, 100)
-                noise = (h(yy * size + xx, 8, sid) % np.uint64(15)).astype(np.int32) - 7
+                bars(img, slide_bars, sid, 100, small=True)        # a slide's own mark: 20-48 x 3-5 px, 19-37 % darker
+                noise = (h(yy * size + xx, 8, sid if slide_noise else did) % np.uint64(15)).astype(np.int32) - 7
                 img += noise[..., None]
                 pages[d * per_deck + j] = np.clip(img, 0, 255).astype(np.uint8)
     return pages
