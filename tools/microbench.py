@@ -53,6 +53,29 @@ def bench_gemm(M, N, K, epi=0, variant=0):
     resid = torch.zeros((M, ocols), dtype=torch.float32, device=dev) if epi == 3 else None
     s = torch.cuda.current_stream().cuda_stream
 
+    if variant not in (0, 3, 7, 9, 12, 13):
+        raise SystemExit(f"variant {variant} was a round-1 experiment (DESIGN.md ledger row 5); it is no longer built")
+    call = lib.vr_op_gemm
+
+    def fn():
+        _lib.check(lib.vr_op_attention(0, P(qkv), ld, qkv.data_ptr() + W * 2, ld, qkv.data_ptr() + 2 * W * 2, ld, P(out),
+                                       out.stride(0), P(cu), P(cu), B, heads, hd, N, causal, 0, hd ** -0.5, s))
+    ms = timeit(fn)
+    fl = 4.0 * B * N * N * W * (0.5 if causal else 1.0)
+    return {"op": f"attn B{B} N{N} h{heads} d{hd} c{causal}", "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+
+
+def bench_gemm(M, N, K, epi=0, variant=0):
+    r256 = lambda x: (x + 255) // 256 * 256
+    A = torch.randn((r256(M), K), device=dev).to(torch.bfloat16)
+    Wt = (torch.randn((r256(N), K), device=dev) * 0.05).to(torch.bfloat16)
+    bias = torch.randn((N,), device=dev)
+    ocols = N // 2 if epi == 4 else N
+    odt = torch.float32 if epi in (2, 3) else torch.bfloat16
+    out = torch.zeros((M, ocols), dtype=odt, device=dev)
+    resid = torch.zeros((M, ocols), dtype=torch.float32, device=dev) if epi == 3 else None
+    s = torch.cuda.current_stream().cuda_stream
+
     if variant in (0, 3, 7, 9, 12, 13):
         call = lib.vr_op_gemm
     else:           # round-1 experiment variants: tools/gemm_lab (python tools/gemm_lab/build.py)

@@ -1,5 +1,5 @@
 """How do isolated GEMM numbers carry over to a stream of kernels?  For the in-tree 256^2 kernel (variant 9),
-the lab's persistent variant (10, if tools/gemm_lab is built) and the vendor GEMM (torch.matmul, yardstick only):
+the one-wave kernel (12) and the vendor GEMM (torch.matmul, yardstick only):
 (a) GEMM launches separated by host syncs, (b) 300 GEMMs back to back, (c) 300 x [LayerNorm, GEMM] back to back
 (the ViT pattern: the A operand is rewritten before every launch); (c) minus the LayerNorm-only stream is the
 GEMM's in-stream cost."""
@@ -15,12 +15,6 @@ from tests.gpu_util import P  # noqa: E402
 from visrag_amd import _lib  # noqa: E402
 
 lib = _lib.load()
-lp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_lab", "libvisrag_gemm_lab.so")
-lab = None
-if os.path.exists(lp):
-    lab = C.CDLL(lp).vr_lab_gemm
-    lab.restype = C.c_int
-    lab.argtypes = lib.vr_op_gemm.argtypes
 s = torch.cuda.current_stream().cuda_stream
 
 
@@ -58,13 +52,13 @@ for (M, N, K) in ((32768, 3456, 1152), (32768, 4352, 1152)):
         if v == "vendor":
             torch.matmul(A, Wt, out=out)
             return
-        f = lib.vr_op_gemm if v in (0, 3, 7, 9, 12, 13) else lab
+        f = lib.vr_op_gemm
         _lib.check(f(0, P(A), K, P(W), K, M, N, K, 0, P(bias), None, 1.0, P(out), N, None, None, 0, v, s))
 
     ln(); torch.cuda.synchronize()
     ln_ms = stream_ms(ln)
     fl = 2.0 * M * N * K
-    for v in [9, 12] + ([10] if lab else []) + ["vendor"]:
+    for v in [9, 12, "vendor"]:
         tot = 0.0
         for it in range(12):
             e0, e1 = ev(), ev()

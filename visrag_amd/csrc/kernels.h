@@ -8,8 +8,8 @@ namespace vr {
 // ---- GEMM (gemm.hip) ---------------------------------------------------------------------
 enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_SWIGLU = 4, EPI_ROPE = 5 };
 // GLDS: 128x128 4-wave tile; 256IL: 256x256 8-wave tile (needs W and A readable up to the next
-// multiple of 256 rows); 192: 256x192 tile for N % 192 == 0; AUTO picks by shape.  (The ids of the
-// retired experiment variants live on in tools/gemm_lab.)
+// multiple of 256 rows); 192: 256x192 tile for N % 192 == 0; AUTO picks by shape.  (The gaps in the ids are
+// retired round-1 experiment variants: DESIGN.md ledger row 5.)
 enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_192 = 7, GEMM_VARIANT_256IL = 9, GEMM_VARIANT_256W = 12,
                    GEMM_VARIANT_192W = 13 };
 
