@@ -1,7 +1,11 @@
-"""Shared by tests/test_gpu_config1xl.py and bench.py's `reference_parity` leg: the encode -> retrieve chain of BASELINE
-config 1 at 512 synthetic pages + the reference's own four input images x 512 synthetic + 2 parquet queries, top-10, against
-the fixture the REFERENCE produced (oracle/gen_golden.py --config1xl: openmatch's DRModelForInference on CPU fp32, then its
-distributed_parallel_retrieve).  Nothing here reads /root/reference: inputs and outputs are the committed fixtures."""
+"""Shared by tests/test_gpu_config1xl.py, tests/test_gpu_config1sep.py and bench.py's `reference_parity` legs: the encode ->
+retrieve chain of BASELINE config 1, top-10, against fixtures the REFERENCE produced (oracle/gen_golden.py: openmatch's
+DRModelForInference on CPU fp32, then its distributed_parallel_retrieve):
+  * config1xl  — 512 unrelated synthetic pages + the reference's own four input images x 512 synthetic + 2 parquet queries
+                 (rank-10 / rank-11 gaps under the bf16 error: 33 strictly gated queries);
+  * config1sep — 51 slide decks x 10 pages + the same four images x 1022 synthetic + 2 parquet queries: the cut falls
+                 BETWEEN decks, 610 queries have a reference gap > 2e-3 and must return the reference's id set.
+Nothing here reads /root/reference: inputs and outputs are the committed fixtures."""
 import json
 import os
 
@@ -12,8 +16,8 @@ QUERY_PREFIX = "Represent this query for retrieving relevant documents: "
 TOL = 1e-3
 
 
-def load_fixture():
-    g = np.load(os.path.join(GOLD, "config1xl_full.npz"))
+def load_fixture(name="config1xl"):
+    g = np.load(os.path.join(GOLD, f"{name}_full.npz"))
     with open(os.path.join(GOLD, "inputs", "manifest.json")) as f:
         man = json.load(f)
     return g, man
@@ -22,9 +26,14 @@ def load_fixture():
 def corpus_and_queries(g, man):
     """The items the reference encoded, in its order: [{'id','text','image'}] for the corpus and for the queries."""
     from PIL import Image
-    from visrag_amd.synth import synth_pages, synth_queries
+    from visrag_amd.synth import synth_deck_pages, synth_pages, synth_queries
     n_pages, n_q = int(g["n_pages"]), int(g["n_queries"])
-    pages = synth_pages(n_pages, size=448, seed=int(g["page_seed"]))
+    if "n_decks" in g.files:              # config1sep: decks of near-identical slides (oracle/gen_golden.py::sep_pages)
+        assert int(g["n_loose"]) == 0 and int(g["n_decks"]) * int(g["per_deck"]) == n_pages
+        pages = synth_deck_pages(int(g["n_decks"]), int(g["per_deck"]), size=448, seed=0, slide_bars=int(g["slide_bars"]),
+                                 slide_noise=bool(int(g["slide_noise"])))
+    else:
+        pages = synth_pages(n_pages, size=448, seed=int(g["page_seed"]))
     corpus = [{"id": f"doc{i}", "text": "", "image": Image.fromarray(p)} for i, p in enumerate(pages)]
     for name, fn in man["docs"]:
         corpus.append({"id": name, "text": "", "image": Image.open(os.path.join(GOLD, "inputs", fn)).convert("RGB")})
@@ -34,7 +43,7 @@ def corpus_and_queries(g, man):
     return corpus, queries
 
 
-def parity_stats(g, P, Q, run, k=None):
+def parity_stats(g, P, Q, run, k=None, fixture="config1xl"):
     """P [516, D], Q [514, D]: this path's embeddings in the fixture's order; run: {qid: {docid: score}} from the drop-in
     retrieve.  Returns the numbers north_star words ("identical top-k doc IDs, cosine scores within 1e-3") — unconditional
     and gated — and raises AssertionError where a bar is missed."""
@@ -74,7 +83,7 @@ def parity_stats(g, P, Q, run, k=None):
                 ok &= abs(Sref[qi, col[da]] - Sref[qi, col[db]]) <= 2 * TOL
         ordered_prefix += ok
     st = {
-        "fixture": "tests/golden/config1xl_full.npz (reference: openmatch DRModelForInference + distributed_parallel_retrieve, CPU fp32)",
+        "fixture": f"tests/golden/{fixture}_full.npz (reference: openmatch DRModelForInference + distributed_parallel_retrieve, CPU fp32)",
         "pages": int(g["n_pages"]), "reference_images": int(g["n_ref_images"]), "queries": nq, "k": k,
         "min_cosine_pages": float(cos_p[: int(g["n_pages"])].min()), "min_cosine_reference_images": float(cos_p[int(g["n_pages"]):].min()),
         "min_cosine_queries": float(cos_q.min()),
@@ -88,11 +97,11 @@ def parity_stats(g, P, Q, run, k=None):
     return st
 
 
-def assert_bars(st):
+def assert_bars(st, min_strict=30):
     assert st["min_cosine_pages"] > 1 - TOL and st["min_cosine_queries"] > 1 - TOL and st["min_cosine_reference_images"] > 1 - TOL, st
     assert st["max_abs_score_error"] < TOL, st
     assert st["max_abs_error_of_returned_scores"] < TOL, st
-    assert st["queries_gated_strict (rank-k / k+1 gap > 2e-3)"] >= 30, st
+    assert st["queries_gated_strict (rank-k / k+1 gap > 2e-3)"] >= min_strict, st
     assert st["strict_id_sets_identical"] == st["queries_gated_strict (rank-k / k+1 gap > 2e-3)"], st
     assert st["queries_tolerance_equivalent"] == st["queries"], st
     assert st["queries_order_consistent_beyond_2tol"] == st["queries"], st

@@ -53,6 +53,40 @@ def test_gemm_192_tile(M, N, K):
         np.testing.assert_allclose(out.numpy(), acc.numpy(), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(100, 192, 64), (128, 384, 128), (2176, 2304, 2304), (2176, 2304, 5760), (1000, 1152, 192), (129, 768, 320)])
+def test_gemm_128w_tile(M, N, K):
+    """Half-height one-wave tiles (gemm128w.hip, variants 14 = 128 x 192, 15 = 128 x 256): residual in place on both, the
+    lookup-free bf16 / GELU / SwiGLU forms on the 256-wide one; K of 1, 2, 3, 5 and 36 / 90 steps walks every exit of the
+    three-stage loop; the decoder's o / down shapes."""
+    A, W, b = _bf(_rand((M, K), 61)), _bf(_rand((N, K), 62, 0.1)), _rand((N,), 63)
+    acc = A.float() @ W.float().T + b
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    r = _rand((M, N), 64)
+    ref = (r + 0.5 * acc).numpy()
+    tol = dict(rtol=1e-5, atol=1e-4 * max(1.0, K / 512))
+    out = op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.5, out_dtype=torch.float32, variant=14).cpu()
+    np.testing.assert_allclose(out.numpy(), ref, **tol)
+    # ... bit-identical to the 256-row kernel's result: the same MFMA chain per output, whatever the tile
+    out13 = op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.5, out_dtype=torch.float32, variant=13).cpu()
+    assert torch.equal(out, out13)
+    if N % 256 == 0:
+        out = op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.5, out_dtype=torch.float32, variant=15).cpu()
+        np.testing.assert_allclose(out.numpy(), ref, **tol)
+        assert torch.equal(op_gemm(Ad, Wd, 0, bias=bd, variant=15), op_gemm(Ad, Wd, 0, bias=bd, variant=12))
+        assert torch.equal(op_gemm(Ad, Wd, 1, bias=bd, variant=15), op_gemm(Ad, Wd, 1, bias=bd, variant=12))
+        np.testing.assert_allclose(op_gemm(Ad, Wd, 1, bias=bd, variant=15).float().cpu().numpy(), torch.nn.functional.gelu(acc).numpy(), rtol=1e-2, atol=2e-2 * max(1.0, K / 512))
+        I = N // 2
+        il = lambda g, u: torch.stack([g.reshape(I // 16, 16, *g.shape[1:]), u.reshape(I // 16, 16, *u.shape[1:])], dim=1).reshape(2 * I, *g.shape[1:])  # noqa: E731
+        Wi, bi = il(W[:I], W[I:]).to(DEV), il(b[:I], b[I:]).to(DEV)
+        sw = torch.nn.functional.silu(acc[:, :I]) * acc[:, I:]
+        o15 = op_gemm(Ad, Wi, 4, bias=bi, out_cols=I, variant=15)
+        np.testing.assert_allclose(o15.float().cpu().numpy(), sw.numpy(), rtol=1e-2, atol=3e-2 * max(1.0, K / 512))
+        assert torch.equal(o15, op_gemm(Ad, Wi, 4, bias=bi, out_cols=I, variant=12))
+    else:
+        with pytest.raises(Exception):
+            op_gemm(Ad, Wd, 3, bias=bd, resid=r.to(DEV), alpha=0.5, out_dtype=torch.float32, variant=15)
+
+
 def test_gemm_identity_asymmetric():
     """A = I (padded), asymmetric W: catches row/col swaps of the MFMA C layout."""
     K = 128

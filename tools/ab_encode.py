@@ -29,7 +29,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 res = []
 for r in range(rounds):
-    enc.set_profile(True)
+    enc.set_profile(int(os.environ.get("AB_PROFILE", "1")))     # 2: the decoder's sub-phases
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         enc.encode_items(items, device_slices=dev, out=out)

@@ -17,15 +17,17 @@ if len(sys.argv) > 1:
 for sh in shapes:
     M, N, K, epi = sh[:4]
     variant, BN = (13, 192) if (epi == 3 and N % 192 == 0) else (12, 256)      # the product's choice for the N = 1152 residual GEMMs
+    BM = 256
     if len(sh) > 4:
-        variant, BN = sh[4], (192 if sh[4] == 13 else 256)
+        variant, BN = sh[4], (192 if sh[4] in (13, 14) else 256)
+    BM = 128 if variant in (14, 15) else 256
     Np = (N + BN - 1) // BN * BN
-    A = torch.randn((M, K), device="cuda").to(torch.bfloat16)
+    A = torch.randn(((M + 255) // 256 * 256, K), device="cuda").to(torch.bfloat16)
     W = (torch.randn((Np, K), device="cuda") * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda")
-    out = torch.zeros((M, N), device="cuda", dtype=torch.float32 if epi in (2, 3) else torch.bfloat16)
+    out = torch.zeros(((M + 255) // 256 * 256, N), device="cuda", dtype=torch.float32 if epi in (2, 3) else torch.bfloat16)
     resid = out if epi == 3 else None
-    tiles = (M // 256) * (Np // BN)
+    tiles = ((M + BM - 1) // BM) * (Np // BN)
     dbg = torch.zeros((tiles, 16), dtype=torch.int64, device="cuda")
     for it in range(3):
         _lib.check(lib.vr_op_gemm(0, P(A), K, P(W), K, M, N, K, epi, P(bias), P(resid), 0.0 if epi == 3 else 1.0, P(out), N, None, P(dbg), 0, variant, s))

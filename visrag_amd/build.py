@@ -18,18 +18,18 @@ from typing import Iterable, List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "gemm_skinny.hip", "gen_persist.hip", "norm.hip", "attention.hip", "attention_w.hip", "attention_small.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip", "search256w.hip",
+SOURCES = ["gemm.hip", "gemm192.hip", "gemm256w.hip", "gemm128w.hip", "gemm_skinny.hip", "gen_persist.hip", "norm.hip", "attention.hip", "attention_w.hip", "attention_small.hip", "patch_embed.hip", "misc.hip", "search.hip", "search256.hip", "search256w.hip",
            "search_small.hip", "search_bigk.hip", "search_exact.hip", "search_band.hip", "hp_text.hip", "resize.hip", "synth.hip", "pack.hip", "engine.hip", "gen_kernels.hip", "gen.hip", "gen_vision.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # attention.hip: relaxed NaN handling only (infinities are honoured: masked scores are -inf).  Without it
 # every fmaxf of an MFMA result is preceded by a canonicalising v_max_f32 x, x (32 extra VALU per tile);
 # same for the clamp of the GELU epilogue (gemm*.hip: one v_max per output value).
 FILE_FLAGS = {"attention.hip": ["-fno-honor-nans"], "attention_w.hip": ["-fno-honor-nans"], "attention_small.hip": ["-fno-honor-nans"], "gemm.hip": ["-fno-honor-nans"], "gemm192.hip": ["-fno-honor-nans"],
-              "gemm256w.hip": ["-fno-honor-nans"], "gen_persist.hip": ["-fno-honor-nans"]}
+              "gemm256w.hip": ["-fno-honor-nans"], "gemm128w.hip": ["-fno-honor-nans"], "gen_persist.hip": ["-fno-honor-nans"]}
 # gemm256w.hip hand-allocates the accumulation registers inside asm statements; hipcc only sees them as clobbers,
 # so if it ever runs out of VGPRs there it parks the overflow in registers that hold results.  The build checks
 # the generated code: outside the kernel's own asm there must be no accumulation-register traffic at all.
-AGPR_CHECKED = {"gemm256w.hip", "search256w.hip", "attention_w.hip"}
+AGPR_CHECKED = {"gemm256w.hip", "gemm128w.hip", "search256w.hip", "attention_w.hip"}
 # ... and whose score MFMAs are asm statements on arch VGPRs: the listing is also walked for operand hazards (mfma_operand_hazards)
 MFMA_HAZARD_CHECKED = {"attention_w.hip"}
 

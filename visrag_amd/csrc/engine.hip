@@ -1074,6 +1074,26 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         }
         if (m->taps_on) ks = 1;          // (taps read h between the projection and the next norm)
     }
+    // Round 6: when half-height tiles fill one round of the chip (T = 2176: 17 x 12 = 204 workgroups of 128 x 192) the
+    // projections run with the FULL K per workgroup on the three-stage one-wave kernel (gemm128w.hip) and add into the
+    // residual stream in place: no fp32 planes, the RMSNorm behind them reads 20 MB instead of moving 88
+#ifndef VR_DEC_PROJ_128W
+#define VR_DEC_PROJ_128W 1
+#endif
+    bool proj_128w = false, gu_128w = false;
+#ifndef VR_DEC_GU_128W
+#define VR_DEC_GU_128W 0
+#endif
+    {
+        // (A/B knob: gate / up on 128 x 256 tiles when the 256-row grid leaves a ragged second round — T = 2176: 405 tiles on
+        // 256 CUs against 765 half-height ones)
+        const long Ngu = 2L * m->Ip, t256 = (long)((T + 255) / 256) * ((Ngu + 255) / 256), t128g = (long)((T + 127) / 128) * (Ngu / 256);
+        gu_128w = VR_DEC_GU_128W && Ngu % 256 == 0 && (t256 % 256) != 0 && (double)t256 / (double)((t256 + 255) / 256 * 256) < 0.85 &&
+                  (double)t128g / (double)((t128g + 255) / 256 * 256) > 0.95;
+        const long t128 = (long)((T + 127) / 128) * (E / 192);
+        proj_128w = VR_DEC_PROJ_128W && E % 192 == 0 && t128 > 128 && t128 <= 256;
+        if (proj_128w) ks = 1;
+    }
     const size_t pstride = (size_t)T * E;
     float* part = m->w_part.as<float>();
     bool pend = false;                   // h still lacks residual_scale * sum(partials)
@@ -1084,6 +1104,10 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
 #define VR_DEC_O_NOSPLIT 0
 #endif
     auto proj = [&](const void* A, int lda, const Linear& L, bool is_o = false) -> int {
+        if (proj_128w) {
+            GemmArgs a = gemm_args(A, lda, L, T, h, E); a.resid = h; a.alpha = c.residual_scale;
+            if (gemm128w_fits(a, 192)) { HIPCHK(launch_gemm(a, EPI_RESID, GEMM_VARIANT_128W_192, s)); return VR_OK; }
+        }
         if (VR_DEC_O_NOSPLIT && is_o && ks > 1 && proj_variant == GEMM_VARIANT_192W) {
             // A/B knob: the o projection (K = E: 36 K-steps) WITHOUT split-K on the 256 x 192 tile — 108 workgroups on 256 CUs,
             // but no fp32 planes: the residual epilogue adds in place and the RMSNorm that follows is the plain one
@@ -1146,7 +1170,10 @@ static int encode_impl(vr_model_t m, const uint8_t* const* slices, const int32_t
         VRCHK(prof_end(m, VR_PROF_DEC_O, 2.0 * T * (double)E * E, s));
         VRCHK(norm(L.ln2.v.as<float>()));
         VRCHK(prof_begin(m, VR_PROF_DEC_GU, s));
-        { GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip); HIPCHK(launch_gemm(a, EPI_SWIGLU, GEMM_VARIANT_AUTO, s)); }
+        {
+            GemmArgs a = gemm_args(m->w_dxn.p, E, L.gu, T, m->w_dact.p, m->Ip);
+            HIPCHK(launch_gemm(a, EPI_SWIGLU, gu_128w && gemm128w_fits(a, 256) ? GEMM_VARIANT_128W_256 : GEMM_VARIANT_AUTO, s));
+        }
         VRCHK(prof_end(m, VR_PROF_DEC_GU, 4.0 * T * (double)E * m->I, s));
         VRCHK(prof_begin(m, VR_PROF_DEC_DOWN, s));
         VRCHK(proj(m->w_dact.p, m->Ip, L.down));
@@ -1651,9 +1678,10 @@ extern "C" int vr_op_gemm(int device_id, const void* A, int32_t lda, const void*
                           int32_t ldo, const int32_t* rope_pos, const float* rope_table, int32_t rope_cols,
                           int32_t variant, void* stream) {
     if (!A || !W || !out) return fail(VR_ERR_INVALID, "NULL argument");
-    if (variant != GEMM_VARIANT_GLDS && variant != GEMM_VARIANT_AUTO && variant != GEMM_VARIANT_192 && variant != GEMM_VARIANT_256IL && variant != GEMM_VARIANT_256W && variant != GEMM_VARIANT_192W)
-        return fail(VR_ERR_INVALID, "variant %d: 0 (128^2 tile), 3 (auto), 7 (256x192 tile), 9 (256^2 tile), 12 / 13 (256^2 / 256x192 tile, one wave per SIMD)", variant);
-    if (((variant == 7 || variant == 13) ? N % 192 : N % 128) || K % 64 || M <= 0) return fail(VR_ERR_INVALID, "need N %% 128 == 0 (192 for variant 7), K %% 64 == 0");
+    if (variant != GEMM_VARIANT_GLDS && variant != GEMM_VARIANT_AUTO && variant != GEMM_VARIANT_192 && variant != GEMM_VARIANT_256IL && variant != GEMM_VARIANT_256W && variant != GEMM_VARIANT_192W &&
+        variant != GEMM_VARIANT_128W_192 && variant != GEMM_VARIANT_128W_256)
+        return fail(VR_ERR_INVALID, "variant %d: 0 (128^2 tile), 3 (auto), 7 (256x192 tile), 9 (256^2 tile), 12 / 13 (256^2 / 256x192 tile, one wave per SIMD), 14 / 15 (128x192 / 128x256 tile, one wave per SIMD)", variant);
+    if (((variant == 7 || variant == 13 || variant == 14) ? N % 192 : N % 128) || K % 64 || M <= 0) return fail(VR_ERR_INVALID, "need N %% 128 == 0 (192 for variant 7), K %% 64 == 0");
     if (epilogue == EPI_RESID && !resid) return fail(VR_ERR_INVALID, "EPI_RESID needs resid");
     if (epilogue == EPI_ROPE && (!rope_pos || !rope_table)) return fail(VR_ERR_INVALID, "EPI_ROPE needs tables");
     VRCHK(set_dev(device_id));

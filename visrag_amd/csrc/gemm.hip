@@ -147,6 +147,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int variant, hipStream_t s) {
     if (variant == GEMM_VARIANT_192) return launch_gemm192(a, epi, s);
     if (variant == GEMM_VARIANT_256W) return launch_gemm256w(a, epi, s);
     if (variant == GEMM_VARIANT_192W) return launch_gemm192w(a, epi, s);
+    if (variant == GEMM_VARIANT_128W_192) return launch_gemm128w(a, epi, 192, s);
+    if (variant == GEMM_VARIANT_128W_256) return launch_gemm128w(a, epi, 256, s);
     if (variant == GEMM_VARIANT_AUTO) {
         // N = 1152 (SigLIP proj / fc2): 6 x 192 columns, big M -> the 256x192 kernel
 #ifndef VR_GEMM_AUTO_192W

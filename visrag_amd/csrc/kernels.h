@@ -10,8 +10,9 @@ enum GemmEpilogue { EPI_BF16 = 0, EPI_GELU = 1, EPI_F32 = 2, EPI_RESID = 3, EPI_
 // GLDS: 128x128 4-wave tile; 256IL: 256x256 8-wave tile (needs W and A readable up to the next
 // multiple of 256 rows); 192: 256x192 tile for N % 192 == 0; AUTO picks by shape.  (The gaps in the ids are
 // retired round-1 experiment variants: DESIGN.md ledger row 5.)
+// 128W_192 / 128W_256: the half-height one-wave tiles of gemm128w.hip (few rows: the decoder's o / down projections).
 enum GemmVariant { GEMM_VARIANT_GLDS = 0, GEMM_VARIANT_AUTO = 3, GEMM_VARIANT_192 = 7, GEMM_VARIANT_256IL = 9, GEMM_VARIANT_256W = 12,
-                   GEMM_VARIANT_192W = 13 };
+                   GEMM_VARIANT_192W = 13, GEMM_VARIANT_128W_192 = 14, GEMM_VARIANT_128W_256 = 15 };
 
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M_pad][lda]
@@ -44,6 +45,10 @@ hipError_t launch_gemm256w(const GemmArgs& a, int epilogue, hipStream_t s);
 bool gemm256w_fits(const GemmArgs& a, int tile_cols);   // its 32-bit LDS-DMA offsets cover both operands
 // its 256x192 form: N % 192 == 0, EPI_RESID and EPI_F32 (incl. ksplit)
 hipError_t launch_gemm192w(const GemmArgs& a, int epilogue, hipStream_t s);
+// 128 x 192 / 128 x 256 tile, one wave per SIMD, three LDS stages (gemm128w.hip): N % tile_cols == 0, no row map / row bias /
+// split K; tile_cols 192: EPI_RESID, 256: EPI_RESID / BF16 / GELU / SWIGLU
+hipError_t launch_gemm128w(const GemmArgs& a, int epilogue, int tile_cols, hipStream_t s);
+bool gemm128w_fits(const GemmArgs& a, int tile_cols);
 
 // M <= 16 rows (gemm_skinny.hip): the decode step's weight streamer; fp32 planes out[split][M][ldo] (+ bias with split 0)
 // swiglu (ksplit 1, 16-row [gate | up] interleaved W): out = bf16 act [M][ldo] = silu(gate) * up instead of a plane
