@@ -769,14 +769,7 @@ hipError_t launch_attention72w(const AttnArgs& a_in, hipStream_t s) {
     static unsigned long long attr = 0;
     set_max_dynamic_lds((const void*)k, AW_SMEM_ALL, attr);
     // persistent: one workgroup per CU (120 KiB of LDS each) walking the units
-    static int cu_of[64] = {0};                                             // per device id
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!cu_of[dev]) {
-        hipDeviceProp_t prop;
-        cu_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int n_cu = cu_of[dev];
+    const int n_cu = device_cu_count();
     const int units = a.B * a.heads * q_tiles;
     hipLaunchKernelGGL(k, dim3(units < n_cu ? units : n_cu), dim3(64 * NW), AW_SMEM_ALL, s, a);
     return hipGetLastError();

@@ -51,6 +51,17 @@ inline void set_max_dynamic_lds(const void* fn, int bytes, unsigned long long& d
         done |= 1ull << dev;
     }
 }
+// CU count of the current device (cached per device id)
+inline int device_cu_count() {
+    static int cu_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cu_of[dev]) {
+        hipDeviceProp_t prop;
+        cu_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cu_of[dev];
+}
 // counted wait + raw barrier: lets LDS-DMA loads younger than the N-th stay in flight across the
 // barrier (__syncthreads() would drain the whole queue)
 #define VR_WAIT_VM_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")

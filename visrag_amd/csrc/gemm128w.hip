@@ -21,6 +21,14 @@
 //   * epilogues: the buffer-descriptor forms of gemm256w_kernel.h on 4 pieces of 32 rows per wave — residual in place
 //     (any NJ), and the lookup-free bf16 / GELU / SwiGLU forms for NJ = 8.  Shapes they do not cover (a column edge, row
 //     maps, row bias, split K) are refused by the launcher: callers keep the 256-row kernels for those.
+//
+// Measured (round 6, DESIGN.md ledger 53-57): K-step 880 clocks warm (768 = the MFMAs alone) with four stages, 930 with three;
+// in the model the o / down launches take 37 / 72 us against 32 / 58 us for the split-K pair they replace (cold weights: a
+// 128-row tile consumes 40 KiB per 0.47 us K-step and HBM answers in ~2 us — more than the LDS can have in flight), the RMSNorm
+// behind them 11.5 instead of 20 us: the step is level, 4.6 GB of plane traffic per step are gone.  Tried on top and dropped:
+// a fifth wave per workgroup touching the operand lines eight K-steps ahead (two waves on one SIMD: K-step 1500 clocks),
+// K-blocked weights (-1.7 / -2.8 us cold), prefetch workgroups on the round's idle CUs streaming the next projection's weights
+// through the memory-side cache (down -4.5 us, gate / up +2.5: level).
 // Roofline: MFMA (2*M*N*K flops per launch).
 #include <cstdlib>
 #include <type_traits>
@@ -93,12 +101,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7FFFFFFF, 0x00020000);
     const unsigned lchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
     const unsigned lofA = (unsigned)(lane >> 3) * (unsigned)p.lda * 2u + lchunk;
-    const unsigned lofW = (unsigned)(lane >> 3) * (unsigned)p.ldw * 2u + lchunk;
-    const unsigned rgA = (unsigned)p.lda * 16u, rgW = (unsigned)p.ldw * 16u;      // bytes per 8-row group
+    constexpr unsigned wstep = (unsigned)(GEMM_BK * 2);      // bytes between K-steps
+    const unsigned wrow = (unsigned)p.ldw * 2u;             // bytes between W rows
+    const unsigned lofW = (unsigned)(lane >> 3) * wrow + lchunk;
+    const unsigned rgA = (unsigned)p.lda * 16u, rgW = wrow * 8u;                  // bytes per 8-row group
     const unsigned sA0 = (unsigned)wave * (unsigned)NI * rgA, sW0 = (unsigned)wave * (unsigned)NJ * rgW;
     char* const dmaA = smem + wave * (NI * 1024);
     char* const dmaW = smem + H_A_BYTES + wave * (NJ * 1024);
-    const unsigned curA = (unsigned)m0 * (unsigned)p.lda * 2u, curW = (unsigned)n0 * (unsigned)p.ldw * 2u;
+    const unsigned curA = (unsigned)m0 * (unsigned)p.lda * 2u, curW = (unsigned)n0 * wrow;
 
     // one of the NR loads of a K-step: d < NI -> A row group d, else W row group d - NI
     auto dma = [&](int stage, int d, unsigned vA, unsigned vW) {
@@ -125,9 +135,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st) {
-            const unsigned kk = st < nk ? (unsigned)(st * GEMM_BK * 2) : H_OOB;
+            const unsigned kA = st < nk ? curA + (unsigned)(st * GEMM_BK * 2) : H_OOB, kW = st < nk ? curW + (unsigned)st * wstep : H_OOB;
 #pragma unroll
-            for (int d = 0; d < NR; ++d) dma(st, d, lofA + (st < nk ? curA : 0u) + kk, lofW + (st < nk ? curW : 0u) + kk);
+            for (int d = 0; d < NR; ++d) dma(st, d, lofA + kA, lofW + kW);
         }
 #define H_Z(n, R, C0, C1, C2, C3) if ((n) < 8 * NI) { W_ZERO(n, R, C0, C1, C2, C3) }
         W_FOR_EACH_ACC(H_Z)
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int k2 = kt + NST - 1;
             // (the loads of the K-steps past the end of K go nowhere: out of the descriptors' range)
             const unsigned vA = lofA + (k2 < nk ? curA + (unsigned)k2 * (GEMM_BK * 2) : H_OOB);
-            const unsigned vW = lofW + (k2 < nk ? curW + (unsigned)k2 * (GEMM_BK * 2) : H_OOB);
+            const unsigned vW = lofW + (k2 < nk ? curW + (unsigned)k2 * wstep : H_OOB);
             __builtin_amdgcn_sched_barrier(0);
             auto aux1 = [&](int sl) {
                 if (sl < 2 * NR && (sl & 1) == 0) {
@@ -323,9 +333,9 @@ static hipError_t launch_h(GemmArgs a, hipStream_t s) {
 #ifdef VR_W_TIMING
     if (const char* e = getenv("VR_H_GM")) a.raster_gm = atoi(e);
 #endif
-    auto k = gemm128w_bf16_kernel<EPI, NJ>;
-    static unsigned long long attr = 0;     // bit d: set on device d
     constexpr int smem = h_smem_bytes<EPI, NJ>();
+    static unsigned long long attr = 0;     // bit d: set on device d
+    auto k = gemm128w_bf16_kernel<EPI, NJ>;
     set_max_dynamic_lds((const void*)k, smem, attr);
     hipLaunchKernelGGL(k, dim3(tn * tm), dim3(256), smem, s, a);
     return hipGetLastError();
