@@ -366,7 +366,8 @@ def test_search_near_duplicate_cluster_is_exact(n_dup, nq, k):
 def test_exact_pass_alone_matches_oracle(nd, nq, dim, k):
     """An error model so pessimistic that NO query can be certified: every query is flagged, its error band is the whole
     index, and the result comes from the band pass alone (indices of up to 8192 rows: every row re-scored by
-    band_select_kernel) or from the exact fp32 pass alone (larger ones: exact_scores_kernel + radix select)."""
+    band_select_kernel), from the exact fp32 pass alone (larger ones: exact_scores_kernel + radix select) or — a handful of
+    queries on the streaming search — from the merge workgroup's own walk over its score row in segments of 8192 rows."""
     C, Q = _unit(nd, dim, 41), _unit(nq, dim, 42)
     ix = HipIndex(dim, nd); ix.add(C)
     ix.set_search_eps(100.0)
@@ -374,8 +375,9 @@ def test_exact_pass_alone_matches_oracle(nd, nq, dim, k):
     sc, ids = ix.search(Q, k)
     st = ix.search_stats()
     kk = min(k, nd)
-    if nd > k + 24:
-        assert st["flagged"] == nq and (st["exact_pass"] == nq if nd > 8192 else st["band_pass"] == nq), st        # (<= 8192 rows: a band-pass round per query)
+    in_place = nq <= 16 and dim % 256 == 0 and dim <= 2560       # the streaming search redoes a flagged query inside its merge workgroup,
+    if nd > k + 24:                                              # whatever the band's size (segments of 8192 rows): no exact-pass launches
+        assert st["flagged"] == nq and (st["exact_pass"] == nq if nd > 8192 and not in_place else st["band_pass"] == nq), st   # (<= 8192 rows: a band-pass round per query)
     _assert_ids_equal_fp64(ids[:, :kk], sc[:, :kk], C, Q, kk)
     if kk < k:
         assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()

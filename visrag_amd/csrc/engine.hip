@@ -1458,6 +1458,9 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
             a.index_bf16 = ix->bf16.p; a.index_f32 = ix->f32.as<float>(); a.n_docs = ix->n; a.dim = dim;
             a.q_bf16 = ix->qbf.p; a.q_f32 = q32 + (size_t)q0 * dim; a.nq = nb; a.k = k;
             a.convert_q = conv_in_kernel ? 1 : 0;
+            // (a handful of queries: the streaming sweep leaves every bf16 score behind — a query its merge cannot certify is
+            // redone by that merge workgroup itself, and none of the fallback launches below is issued)
+            if (conv_in_kernel) { a.score_rows = ix->sbuf.as<float>(); a.ld_scores = (size_t)ldS; }
             a.eps_data = ix->eps_rel == -2.f ? 1 : 0;
             a.eps_rel = a.eps_data ? 0.f : ix->eps_rel;
             a.acc_rel = search_acc_rel(dim);
@@ -1495,7 +1498,7 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
                 HIPCHK(launch_search(a, s));
             }
             if (prof) HIPCHK(hipEventRecord(ix->prof_ev[4], s));
-            if (a.eps_data || a.eps_rel >= 0.f) {
+            if ((a.eps_data || a.eps_rel >= 0.f) && !a.score_rows) {
                 // whatever the merge flagged (nothing, normally: every kernel below leaves at once), `slots` queries per pass:
                 // bf16 score rows of the flagged queries (GEMM over their compacted bf16 rows, row count on the device) ->
                 // every row inside a query's error band re-scored in fp32 (search_band.hip) -> what is left (bands beyond

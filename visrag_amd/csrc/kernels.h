@@ -237,6 +237,9 @@ struct SearchArgs {
     float* out_scores; int64_t* out_ids;               // [nq][k]
     float* thr_init;                                   // workspace [nq_pad] or null (no pre-pass)
     unsigned long long* cand_keys;                     // 256-tile sweep scratch [nq_pad256][n_chunks][2][64] or null
+    float* score_rows; size_t ld_scores;               // streaming search (nq <= 16) only: the sweep writes EVERY bf16-MFMA score,
+                                                       // [16][ld_scores] (ld_scores % 256 == 0, >= n_docs), and a query its merge cannot
+                                                       // certify is redone in place by its own merge workgroup (search_band.h)
     // ---- certification of the candidate selection (search_common.h: certify_tail)
     const float* thr_used;           // thresholds the sweep STARTED from (set by the launcher; null: none)
     float eps_rel;                   // >= 0: |bf16-MFMA score - fp32 score| <= eps_rel * |q| * dmax (the caller's model);

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "gemm_core.h"
+#include "search_band.h"
 #include "search_common.h"
 #include "kernels.h"
 
@@ -195,8 +196,11 @@ __global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict
 // NT threads: 1024 for the streaming kernel's handful of queries — the chip is empty next to these <= 16 workgroups, and
 // the fp32 re-scoring of a query's 16..40 candidate rows (9 KB each, a memory round trip per row and wave) is the longest
 // chain of the whole search: sixteen waves take it in one or two rounds instead of four to ten.
+// With the sweep's score rows at hand (SearchArgs::score_rows: the streaming kernel writes them) a query that cannot be
+// certified is redone HERE, by the same workgroup (search_band.h; dynamic LDS: BandLds) — nothing is launched behind the merge.
 template <int KP, int NT>
 __global__ __launch_bounds__(NT) void search_merge_wg_kernel(SearchArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char band_smem[];
     constexpr int GD = KP + MERGE_GD_EXTRA < 64 ? KP + MERGE_GD_EXTRA : 64;
     __shared__ uint64_t lm[NT];
     __shared__ uint64_t surv[MERGE_CAP], exact_w[MERGE_CAP];
@@ -283,8 +287,14 @@ __global__ __launch_bounds__(NT) void search_merge_wg_kernel(SearchArgs p) {
     const float coverB = n > 64 ? key_score(cand[63]) : (thr == KEY_NONE ? -INFINITY : key_score(thr));
     float dropB = drop_s ? orderable_f32(drop_s) : -INFINITY;
     if (p.thr_used) dropB = fmaxf(dropB, p.thr_used[q]);
-    certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
-                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); }, surv, exact_w);
+    const bool in_place = p.score_rows != nullptr;
+    const bool flagged = certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
+                                          [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); }, surv, exact_w, in_place);
+    if (in_place && flagged) {                           // workgroup-uniform
+        __syncthreads();
+        const float tau = tau_s;
+        band_pass_in_place<NT>(p, q, tau, p.score_rows + (size_t)q * p.ld_scores, *reinterpret_cast<BandLds*>(band_smem), &x_s);
+    }
 }
 
 int search_kprime(int k) {
@@ -361,8 +371,16 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (a.prof_ev && (e = hipEventRecord(a.prof_ev[3], s)) != hipSuccess) return e;
-    if (search_uses_stream(a.nq, a.dim)) hipLaunchKernelGGL((search_merge_wg_kernel<KP, 1024>), dim3(a.nq), dim3(1024), 0, s, am);
-    else hipLaunchKernelGGL((search_merge_wg_kernel<KP, 256>), dim3(a.nq), dim3(256), 0, s, am);
+    if (search_uses_stream(a.nq, a.dim)) {
+        auto km = search_merge_wg_kernel<KP, 1024>;
+        const int lds = am.score_rows ? (int)sizeof(BandLds) : 0;
+        static unsigned long long mattr = 0;    // bit d: set on device d
+        set_max_dynamic_lds((const void*)km, (int)sizeof(BandLds), mattr);
+        hipLaunchKernelGGL(km, dim3(a.nq), dim3(1024), lds, s, am);
+    } else {
+        am.score_rows = nullptr;
+        hipLaunchKernelGGL((search_merge_wg_kernel<KP, 256>), dim3(a.nq), dim3(256), 0, s, am);
+    }
     return hipGetLastError();
 }
 

@@ -23,67 +23,28 @@
 //      retrieval problem any more) goes on a second list, and the exact fp32 pass (search_exact.hip) redoes it.
 //
 // Roofline: the GEMM is MFMA-bound (2 x flagged x rows x dim), the selection HBM / L2 (score rows + union rows).
-#include "kernels.h"
-#include "search_common.h"
+#include "search_band.h"
 
 namespace vr {
 
-constexpr int BAND_MAX = 8192;      // rows a query's band may hold (its keys: 64 KiB of LDS)
 constexpr int BAND_NT = 512;        // threads (8 waves)
-constexpr int BAND_NR = 3;          // rows in flight per wave
 
 int search_band_max() { return BAND_MAX; }
-
-struct BandLds {                    // dynamic LDS image: 96 KiB, one workgroup per CU
-    uint64_t keys[BAND_MAX];        // the band's exact keys
-    uint32_t cand[BAND_MAX];        // its row ids
-};
 
 __global__ __launch_bounds__(BAND_NT) void band_select_kernel(SearchArgs p, const float* __restrict__ S, size_t ldS, int sub,
                                                               int max_slots) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BandLds& L = *reinterpret_cast<BandLds*>(smem_raw);
     __shared__ int ucnt_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = BAND_NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int n_slots = min(max(p.flag_count[0] - sub, 0), max_slots);
     const int n_docs = (int)p.n_docs, k = p.k, dim = p.dim, nv = dim >> 2;
     for (int slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
         const int q = p.flag_list[sub + slot];
         const float tau = p.flag_tau[sub + slot];
         const float* row = S + (size_t)slot * ldS;
-        __syncthreads();                                                 // (LDS of the previous slot is free)
-        if (tid == 0) ucnt_s = 0;
-        __syncthreads();
-        // ---- 1. ONE pass over the score row: the band's row ids.  16 bytes per thread and load, four loads requested before the
-        //         first is looked at (the ballots below keep the compiler from hoisting them itself: without this a lone
-        //         workgroup pays a memory round trip per 8 KiB of scores)
-        for (int i0 = 0; i0 < n_docs; i0 += 16 * BAND_NT) {
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 4 * BAND_NT + tid * 4;
-                v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                if (i < n_docs) v[u] = *reinterpret_cast<const f32x4*>(row + i);          // (rows are padded to 256 floats)
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 4 * BAND_NT + tid * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool in = i + e < n_docs && v[u][e] >= tau;
-                    const unsigned long long b = __ballot(in);
-                    if (b == 0ull) continue;                             // wave-uniform
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&ucnt_s, __popcll(b));
-                    base = __shfl(base, 0, 64);
-                    const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
-                    if (in && pos < BAND_MAX) L.cand[pos] = (uint32_t)(i + e);
-                }
-            }
-        }
-        __syncthreads();
-        const int n_band = __builtin_amdgcn_readfirstlane(ucnt_s);
+        // ---- 1. ONE pass over the score row: the band's row ids
+        const int n_band = band_gather<BAND_NT>(row, 0, n_docs, tau, L, &ucnt_s);
         if (n_band > BAND_MAX || !(tau > -INFINITY)) {                   // workgroup-uniform: the exact fp32 pass
             if (tid == 0) {
                 const int pos = atomicAdd(p.flag2_count, 1);
@@ -92,58 +53,19 @@ __global__ __launch_bounds__(BAND_NT) void band_select_kernel(SearchArgs p, cons
             }
             continue;
         }
-        // ---- 2. exact fp32 scores: a wave takes rows wave, wave + NW, ...; BAND_NR rows in flight per wave (a row is nine
-        //         1 KiB loads; the re-scoring is a chain of memory round trips)
+        // ---- 2. exact fp32 scores
         f32x4 qv[MERGE_MAXV];
         load_query_regs(qv, p.q_f32 + (size_t)q * dim, nv, lane);
-        auto load_row = [&](f32x4 (&dv)[MERGE_MAXV], int cidx) {
-            if (cidx >= n_band) return;
-            const f32x4* dr = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)L.cand[cidx] * dim);
-#pragma unroll
-            for (int i = 0; i < MERGE_MAXV; ++i) {
-                const int cc = lane + i * 64;
-                dv[i] = (cc < nv) ? dr[cc] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        auto score_row = [&](const f32x4 (&dv)[MERGE_MAXV], int cidx) {
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < MERGE_MAXV; ++i) {
-                const int cc = lane + i * 64;
-                if (cc < nv) a = dot_chunk(qv[i], dv[i], a);              // the chain of dot_lane(q, row)
-            }
-            a = wave_sum(a);
-            if (lane == 0) L.keys[cidx] = make_key(a, L.cand[cidx]);
-        };
-        f32x4 dr_[BAND_NR][MERGE_MAXV];
-#pragma unroll
-        for (int r = 0; r < BAND_NR; ++r) load_row(dr_[r], wave + r * NW);
-        for (int cidx = wave; cidx < n_band; cidx += BAND_NR * NW) {
-#pragma unroll
-            for (int r = 0; r < BAND_NR; ++r) {
-                if (cidx + r * NW < n_band) score_row(dr_[r], cidx + r * NW);
-                load_row(dr_[r], cidx + (r + BAND_NR) * NW);
-            }
-        }
-        __syncthreads();
+        band_rescore<BAND_NT>(p, qv, n_band, L);
         // ---- 3. the top k
         uint64_t* kq = L.keys;
         if (k <= 64) {
             // the best 64 without a workgroup barrier per sorting stage: every wave folds its share of the keys into a sorted
             // top-64 (register network), wave 0 merges the eight lists
             uint64_t best = KEY_NONE;
-            for (int base = wave * 64; base < n_band; base += NW * 64) {
-                const uint64_t key = base + lane < n_band ? kq[base + lane] : KEY_NONE;
-                best = base == wave * 64 ? wave_sort_desc(key) : wave_merge_top64(best, key, lane);
-            }
-            __syncthreads();                                             // (everyone has read its keys: the head of kq is reused)
-            kq[wave * 64 + lane] = best;
-            __syncthreads();
-            if (wave == 0) {
-                uint64_t top = kq[lane];
-                for (int w = 1; w < NW; ++w) top = wave_merge_top64(top, kq[w * 64 + lane], lane);
-                if (lane < k) emit_slot(p, q, lane, top);
-            }
+            bool first = true;
+            band_fold64<BAND_NT>(L, n_band, best, first);
+            band_emit64<BAND_NT>(p, q, L, best, first);
             continue;
         }
         int n2 = 64;

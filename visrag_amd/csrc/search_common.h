@@ -193,10 +193,12 @@ __device__ __forceinline__ void block_bitonic_desc(uint64_t* keys, int n, int ti
     }
 }
 
+// Returns whether the query could NOT be certified (workgroup-uniform; *sh_tau holds its tau).  defer_flag: the caller redoes
+// such a query itself (the handful-of-queries merge: search_band.h) — it is counted, but not put on the flag list.
 template <int KP, typename Regather>
-__device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
+__device__ __forceinline__ bool certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
                                              float coverB, float dropB, float* sh_tau, int* sh_x, Regather regather,
-                                             const uint64_t* surv, uint64_t* exact_w) {
+                                             const uint64_t* surv, uint64_t* exact_w, bool defer_flag = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int nv = p.dim >> 2;
     const float* qrow = p.q_f32 + (size_t)q * p.dim;
@@ -249,7 +251,7 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
                 if (lane < p.k) emit_slot(p, q, lane, best);
                 if (lane == 0 && p.stats) atomicAdd(&p.stats[1], 1u);
             }
-            return;
+            return false;
         }
         coverB = n > 64 ? key_score(cand[63]) : -INFINITY;
     }
@@ -272,7 +274,9 @@ __device__ __forceinline__ void certify_tail(const SearchArgs& p, int q, const u
         }
     }
     // (coverB / dropB / tau / x are workgroup-uniform: every thread evaluates the same predicate)
-    flag_query(p, q, certify && !(below(coverB, tau) && below(dropB, tau)), tau, sh_x);
+    const bool flagged = certify && !(below(coverB, tau) && below(dropB, tau));
+    if (!defer_flag) flag_query(p, q, flagged, tau, sh_x);
+    return flagged;
 }
 
 }  // namespace vr

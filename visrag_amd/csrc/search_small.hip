@@ -126,6 +126,10 @@ __global__ __launch_bounds__(512) void search_stream_kernel(SearchArgs p, int ro
                 }
             }
             // D[doc = fq*4 + r][query = fr]
+            // every score leaves for the band pass a flagged query's merge workgroup may need (search_band.h): 16 bytes per lane,
+            // 6.4 MB per search next to the 460 MB read (the rows of a strip past n_docs repeat the last row: never looked at)
+            if (p.score_rows && fr < p.nq)
+                *reinterpret_cast<f32x4*>(p.score_rows + (size_t)fr * p.ld_scores + (size_t)(row_lo + (int64_t)strip * 16 + fq * 4)) = acc;
             if (fr < p.nq) {
                 const float th = L.thr[fr];
 #pragma unroll
