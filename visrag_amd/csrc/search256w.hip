@@ -40,12 +40,28 @@ constexpr unsigned SW_OOB = 0x80000000u;
 constexpr int SW_HL_CAP = 64;                      // slots per half-list (= search256.hip's)
 constexpr int SW_HL_TRIG = 48;                     // compact a half-list longer than this (a strip adds <= 16)
 constexpr int SW_SMEM = 2 * SW_STAGE + 256 * 4 + 256;    // stages + thresholds + per-query "a list was compacted" bytes
+// timing diagnostics only (tagged builds, tools/variant.sh; results are wrong): 1 no filter epilogue, 2 filter without its stores / counters
+#ifndef SW_DBG
+#define SW_DBG 0
+#endif
 
 __device__ __forceinline__ uint64_t sw_ld_key(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void sw_st_key(unsigned long long* p, uint64_t v) {
     __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// OR of a 32-bit value over the wave, as a scalar: row_shr 1 / 2 / 4 / 8 leave a row's OR in its lane 15, row_bcast 15 / 31
+// carry it on to lane 63 (OR is idempotent: no bank masks needed)
+__device__ __forceinline__ uint32_t sw_wave_or(uint32_t x) {
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
 __device__ __forceinline__ void* sw_uniform_ptr(const char* q) {
@@ -231,29 +247,45 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
             const int doc0 = tile * 256;
             const uint32_t below = (1u << fr) - 1u;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < ((SW_DBG & 1) ? 0 : 8); ++i) {
                 f32x4 v[8];
 #define SW_RD(n, R, C0, C1, C2, C3) if (((n) >> 3) == i) W_READ(v[(n) & 7], C0, C1, C2, C3);
                 W_FOR_EACH_ACC(SW_RD)
 #undef SW_RD
                 const int doc = doc0 + wm * 128 + i * 16 + fr;
                 const bool valid = doc < p.n_docs;
+                // The lane's 32 scores of the strip against their thresholds WITHOUT a branch or a scalar-register round trip per
+                // value: the sign of s - thr is shifted into a mask (v_sub + v_alignbit, bit 31 - (j * 4 + r) = "below"), the
+                // wave's OR of the pass masks comes back as ONE scalar (six DPP steps + a readlane), and only the (j, r) columns
+                // whose bit is set in it — ~9 of 32 with the 4096-row pre-pass — take the ballot / append path.  Round 6,
+                // tools/r6/sweep_anatomy.sh: a compare -> ballot -> `s_cbranch_vccz` per value (v_cmp, s_and, v_cndmask, v_cmp_ne,
+                // branch: every step waits for the other pipe) cost 6.4 us of a tile's 12.2 us filter, the appends 5.3.
+                uint32_t mlow = 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int qn = wn * 128 + j * 16 + fq * 4;
-                    const f32x4 th = *reinterpret_cast<const f32x4*>(&thr_lds[qn]);
+                    const f32x4 th = *reinterpret_cast<const f32x4*>(&thr_lds[wn * 128 + j * 16 + fq * 4]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float s = v[j][r];
-                        const bool pass = valid && s >= th[r];
-                        const unsigned long long bal = __ballot(pass);
-                        if (bal) {                              // wave-uniform
-                            const uint32_t grp = (uint32_t)(bal >> (fq * 16)) & 0xFFFFu;
-                            if (pass) {
-                                const int pos = (int)((c8[j] >> (8 * r)) & 0xFFu) + __popc(grp & below);
-                                sw_st_key(gw + (size_t)(qn + r) * gq + pos, make_key(s, (uint32_t)doc));
+                    for (int r = 0; r < 4; ++r) mlow = __builtin_amdgcn_alignbit(mlow, __builtin_bit_cast(uint32_t, v[j][r] - th[r]), 31);
+                }
+                const uint32_t mpass = valid ? ~mlow : 0u;
+                const uint32_t um = (SW_DBG & 2) ? 0u : sw_wave_or(mpass);
+                if (um) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int qn = wn * 128 + j * 16 + fq * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t bit = 0x80000000u >> (j * 4 + r);
+                            if (um & bit) {                         // scalar test: some lane of the wave has a survivor in column (j, r)
+                                const bool pass = (mpass & bit) != 0u;
+                                const unsigned long long bal = __ballot(pass);
+                                const uint32_t grp = (uint32_t)(bal >> (fq * 16)) & 0xFFFFu;
+                                if (pass) {
+                                    const int pos = (int)((c8[j] >> (8 * r)) & 0xFFu) + __popc(grp & below);
+                                    sw_st_key(gw + (size_t)(qn + r) * gq + pos, make_key(v[j][r], (uint32_t)doc));
+                                }
+                                c8[j] += (uint32_t)__popc(grp) << (8 * r);
                             }
-                            c8[j] += (uint32_t)__popc(grp) << (8 * r);
                         }
                     }
                 }
