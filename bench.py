@@ -271,6 +271,7 @@ def main():
              "stages_ms": {k: round(v, 4) for k, v in stages.items() if k != "calls"},
              "sweep_kernel_tflops": round(flops / max(stages["sweep"], 1e-9) / 1e9, 1),
              "error_model": {k: float(f"{v:.4g}") for k, v in index.error_model().items()},
+             "plan": index.search_plan(args.queries),      # (prepass_chunks > 0: the pre-pass owns its 16 sampled tiles, the sweep skips them)
              "certification": {"certified_at_once": round(cert["certified"] / n_cert, 4),
                                "certified_after_extended_rescoring": round(cert["certified_extended"] / n_cert, 4),
                                "band_pass": round(cert["band_pass"] / n_cert, 4),

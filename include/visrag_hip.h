@@ -225,6 +225,11 @@ int vr_index_error_model(vr_index_t ix, float* out4);
  * group: those whose candidates had to be gathered a second time, of the flagged: those whose band
  * exceeded 8192 rows and went through the exact fp32 pass}. */
 int vr_index_search_stats(vr_index_t ix, int64_t* out6, int32_t reset);
+/* How a search of `nq` queries (k <= 26) over the rows added so far would be laid out: out4 = {list chunks per query,
+ * of them the chunks that belong to the threshold pre-pass (0, or 8 when the pre-pass OWNS its sample: its 16 sampled 256-row
+ * tiles are scored once, their survivors kept in lists of their own, and the sweep skips them), workgroup chunks of the
+ * sweep, index tiles (256 rows) per workgroup chunk}.  Introspection only (tests, bench.py's `search.plan`). */
+int vr_index_search_plan(vr_index_t ix, int32_t nq, int32_t* out4);
 /* Per-stage HIP-event times of vr_index_search (k <= 26), summed over calls since enabling:
  * ms5 = {query conversion, threshold pre-pass, sweep, merge + re-scoring, band + exact pass}.
  * While enabled every call ends with an event synchronisation. */

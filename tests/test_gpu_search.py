@@ -775,3 +775,56 @@ def test_corpus_sharded_retrieve_two_ranks_on_one_gpu(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def _prepass_spot_rows(nd, spots):
+    """rows of the owning pre-pass's sampled tiles (kernels.h: index tile k * S + S - 1, S = tiles // 16)"""
+    tiles = (nd + 255) // 256
+    S = tiles // 16
+    return np.concatenate([np.arange((k * S + S - 1) * 256, min(nd, (k * S + S) * 256)) for k in spots])
+
+
+@pytest.mark.parametrize("nd,nq,dim,k", [(33024, 300, 256, 10), (33024, 1000, 128, 26), (36700, 1000, 128, 10), (100000, 1000, 256, 10),
+                                          (47000, 520, 384, 16)])
+def test_prepass_that_owns_its_sample(nd, nq, dim, k):
+    """Round 6 (search.hip: search_prepass_own_kernel): where it shortens the sweep, the threshold pre-pass keeps every score of
+    its 16 sampled 256-row tiles and appends the rows that reach the threshold to lists of its own; the sweep skips those tiles.
+    Shapes where the plan says so (incl. 36 700 rows: the last, ragged tile is a sampled one), every query's best row planted
+    INSIDE a sampled tile for a third of the queries, next to one for another third: ids equal an fp64 brute force."""
+    C, Q = _unit(nd, dim, 71), _unit(nq, dim, 72)
+    spot = _prepass_spot_rows(nd, range(16))
+    rng = np.random.default_rng(73)
+    for q in range(0, nq, 3):                                   # best row inside a sampled tile
+        r = int(rng.choice(spot)); C[r] = Q[q] + 0.3 * C[r]; C[r] /= np.linalg.norm(C[r])
+    for q in range(1, nq, 3):                                   # ... and just outside one (the row in front of the tile / behind it)
+        r = int(rng.choice([spot[0] - 1, spot[255] + 1, spot[256 * 7] - 1])); C[r] = Q[q] + 0.3 * C[r]; C[r] /= np.linalg.norm(C[r])
+    ix = HipIndex(dim, nd); ix.add(C)
+    plan = ix.search_plan(nq)
+    assert plan["prepass_chunks"] == 8 and plan["list_chunks"] == plan["sweep_chunks"] + 8, plan
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    assert st["uncertified"] == 0 and st["certified"] + st["certified_extended"] + st["flagged"] == nq, st
+    assert st["flagged"] <= nq // 50, st                       # random rows: the lists prove the result, nothing behind the sweep
+    assert ix.search_plan(16)["prepass_chunks"] == 0 and ix.search_plan(1)["prepass_chunks"] == 0
+
+
+def test_prepass_own_lists_overflow_is_flagged_not_wrong():
+    """More sampled rows reach a query's threshold than its own lists hold (1024): five sampled tiles are 1280 copies of one
+    vector that is the query's best row — twenty fold groups tie at the top, the threshold IS that score, all 1280 pass.  The
+    lists are then declared incomplete (thr_cert = +inf) and the band pass redoes the query: the ten LOWEST row ids of the copies."""
+    nd, nq, dim, k = 33024, 300, 256, 10
+    C, Q = _unit(nd, dim, 81), _unit(nq, dim, 82)
+    rows = _prepass_spot_rows(nd, [2, 3, 4, 9, 15])
+    assert len(rows) == 1280
+    C[rows] = Q[0]
+    C[777] = Q[0]                                               # one more copy in a swept tile, with a lower id than any sampled one
+    ix = HipIndex(dim, nd); ix.add(C)
+    assert ix.search_plan(nq)["prepass_chunks"] == 8
+    ix.search_stats(reset=True)
+    sc, ids = ix.search(Q, k)
+    st = ix.search_stats()
+    assert list(ids[0]) == [777] + rows[:9].tolist(), ids[0]
+    _assert_ids_equal_fp64(ids, sc, C, Q, k)
+    assert st["flagged"] >= 1 and st["uncertified"] == 0, st

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vr_index_set_search_eps": (C.c_int, [_vp, _f32]),
     "vr_index_search_stats": (C.c_int, [_vp, C.POINTER(_i64), _i32]),
     "vr_index_error_model": (C.c_int, [_vp, C.POINTER(_f32)]),
+    "vr_index_search_plan": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
     "vr_synth_pages": (C.c_int, [C.c_int, _vp, _i32, _i32, _i64, _i64, _vp]),
     "vr_streams_overlap": (C.c_int, [C.c_int, _vp, _vp, C.POINTER(C.c_int32)]),
     "vr_index_set_search_profile": (C.c_int, [_vp, _i32]),

@@ -1358,6 +1358,17 @@ extern "C" int vr_index_search_stats(vr_index_t ix, int64_t* out6, int32_t reset
     return VR_OK;
 }
 
+extern "C" int vr_index_search_plan(vr_index_t ix, int32_t nq, int32_t* out4) {
+    if (!ix || !out4 || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
+    const bool stream = search_uses_stream(nq, ix->dim);
+    const int own = stream ? 0 : search_prepass_owned(ix->n, nq, ix->dim);
+    const int sweep = stream ? search_stream_chunks() : search_num_chunks(ix->n - (own ? (int64_t)SEARCH_PRE_SPOTS * 256 : 0), nq);
+    const int64_t tile = search_uses_256(nq) ? 256 : 128;
+    const int64_t tiles = (ix->n + tile - 1) / tile - (own ? SEARCH_PRE_SPOTS : 0);
+    out4[0] = sweep + own; out4[1] = own; out4[2] = sweep; out4[3] = stream ? 0 : (int)((tiles + sweep - 1) / sweep);
+    return VR_OK;
+}
+
 extern "C" int vr_index_error_model(vr_index_t ix, float* out4) {
     if (!ix || !out4) return fail(VR_ERR_INVALID, "NULL argument");
     VRCHK(set_dev(ix->device));
@@ -1409,7 +1420,7 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
     const int64_t slots = bigk ? 256 : std::min<int64_t>(nqp, std::max<int64_t>(16, (((int64_t)1 << 27) / ldS) / 16 * 16));
     if (ix->qcap < nqp) {
         VRCHK(ix->qbf.alloc((size_t)nqp * dim * 2));
-        VRCHK(ix->thr.alloc((size_t)nqp * 4));
+        VRCHK(ix->thr.alloc((size_t)nqp * 8));            // thresholds | what the lists are complete down to (thr_cert)
         ix->qcap = nqp;
     }
     const float* q32 = queries;
@@ -1481,8 +1492,13 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
                 HIPCHK(launch_gemm(g, EPI_F32, GEMM_VARIANT_AUTO, s));
                 HIPCHK(launch_search_bigk(a, ix->sbuf.as<float>(), (size_t)ldS, 0, nb, s));
             } else {
-                a.n_chunks = search_uses_stream(nb, dim) ? search_stream_chunks() : search_num_chunks(ix->n, nb);
+                // (the 256-tile sweep over >= 128 index tiles: the threshold pre-pass owns its 16 sampled tiles — scored once, its
+                // survivors in 8 list chunks of their own behind the sweep's — and the sweep walks the rest: search.hip)
+                a.pre_own_chunks = search_uses_stream(nb, dim) ? 0 : search_prepass_owned(ix->n, nb, dim);
+                a.n_chunks = search_uses_stream(nb, dim) ? search_stream_chunks()
+                             : search_num_chunks(ix->n - (a.pre_own_chunks ? (int64_t)SEARCH_PRE_SPOTS * 256 : 0), nb) + a.pre_own_chunks;
                 a.thr_init = ix->thr.as<float>();
+                a.thr_cert = ix->thr.as<float>() + ix->qcap;
                 const int64_t need = std::max<int64_t>(nbp * a.n_chunks * kp, nbp * search_prepass_floats());
                 if (ix->ccap < need) {
                     VRCHK(ix->cs.alloc((size_t)need * 4));

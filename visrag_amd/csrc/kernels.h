@@ -236,6 +236,12 @@ struct SearchArgs {
     float* cand_scores; int* cand_ids; int n_chunks;   // workspace [nq_pad][n_chunks][KP]
     float* out_scores; int64_t* out_ids;               // [nq][k]
     float* thr_init;                                   // workspace [nq_pad] or null (no pre-pass)
+    int pre_own_chunks;                                // 0, or the number of list chunks at the END of n_chunks that belong to the threshold
+                                                       // pre-pass (search_prepass_owned): its sampled 256-row tiles are scored ONCE — the pre-pass
+                                                       // keeps every score, appends the rows >= the threshold to those lists itself, and the
+                                                       // sweep (n_chunks - pre_own_chunks workgroup chunks) skips the sampled tiles
+    float* thr_cert;                                   // workspace [nq_pad] (pre_own_chunks > 0): what the lists are complete down to — the
+                                                       // threshold, or +inf for a query whose pre-pass list overflowed (exact ties)
     unsigned long long* cand_keys;                     // 256-tile sweep scratch [nq_pad256][n_chunks][2][64] or null
     float* score_rows; size_t ld_scores;               // streaming search (nq <= 16) only: the sweep writes EVERY bf16-MFMA score,
                                                        // [16][ld_scores] (ld_scores % 256 == 0, >= n_docs), and a query its merge cannot
@@ -259,7 +265,11 @@ struct SearchArgs {
 };
 constexpr int SEARCH_PROF_EVENTS = 6;   // start | queries converted | thresholds | sweep | merge | exact pass
 int search_kprime(int k);            // candidates kept per (query, chunk); 0 if k unsupported
-int search_num_chunks(int64_t n_docs, int nq);
+int search_num_chunks(int64_t n_docs, int nq);         // workgroup chunks of the sweep (over the rows it sweeps: see search_prepass_owned)
+// 8 when the threshold pre-pass OWNS its sample (the 256-tile sweep on the one-wave kernel, >= 128 index tiles), else 0: the caller
+// adds it to n_chunks (list chunks) and sets SearchArgs::pre_own_chunks / thr_cert
+int search_prepass_owned(int64_t n_docs, int nq, int dim);
+constexpr int SEARCH_PRE_SPOTS = 16;    // sampled 256-row tiles of the owning pre-pass: tile k * S + S - 1, S = index tiles / 16
 int search_prepass_floats();         // floats of cand_scores per (padded) query the threshold pre-pass needs
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
 bool search_uses_stream(int nq, int dim);   // nq <= 16: index streamed through registers (search_small.hip)
@@ -269,7 +279,7 @@ bool search_uses_256(int nq);         // more than 128 queries: main sweep on th
 hipError_t launch_sweep256(const SearchArgs& a, int kp, const float* thr, hipStream_t s);
 // the same sweep on the one-wave-per-SIMD tile (search256w.hip; dim % 128 == 0): sweep only, launch_sweep256 merges
 bool sweep256w_ok(const SearchArgs& a);
-hipError_t launch_sweep256w(const SearchArgs& a, int kp, const float* thr, hipStream_t s);
+hipError_t launch_sweep256w(const SearchArgs& a, int kp, const float* thr, hipStream_t s);   // (honours pre_own_chunks)
 // k > 26 (search_bigk.hip): radix select over the block's score rows S + exact re-score; k <= search_bigk_max()
 int search_bigk_max();
 hipError_t launch_search_bigk(const SearchArgs& a, const float* S, size_t ldS, int q0, int nq_block, hipStream_t s);

@@ -186,6 +186,102 @@ __global__ __launch_bounds__(256) void search_thr_kernel(const float* __restrict
 }
 
 
+// ---- the pre-pass that OWNS its sample (round 6; the 256-tile sweep on the one-wave kernel, >= 128 index tiles) -----------
+// The plain pre-pass scores 4096 sampled rows and throws the scores away: the sweep scores them again.  Here the sample is
+// SEARCH_PRE_SPOTS = 16 whole 256-row index tiles (tile k * S + S - 1, S = tiles / 16: the same 4096 rows spread over the index),
+// every score is kept ([query][4096] fp32 behind the group maxima), and search_thr_own_kernel — after the threshold — appends
+// the sampled rows that reach it to the query's OWN lists: the last pre_own_chunks list chunks, 16 half-lists = 1024 slots, in
+// the format of the sweep's.  The sweep walks the other tiles only.  1k x 100k: 391 - 16 = 375 tiles over 64 chunks — six tiles
+// per workgroup instead of seven.  Rows >= thr sit in fold groups (64 rows) whose maximum is >= thr: the KP - 1 groups above the
+// KP-th maximum plus the groups that tie with it — ~18 rows on model embeddings, at most 1024 for KP = 16 without exact ties.  More
+// than 1024 (KP = 32 in its worst case, duplicate rows): the query's lists are declared incomplete (thr_cert = +inf: the merge
+// cannot certify, the band pass redoes the query) — rigorous, just slow.
+__global__ __launch_bounds__(256) void search_prepass_own_kernel(SearchArgs p, int q_tiles, int pre_step, float* __restrict__ gmax,
+                                                                 float* __restrict__ gscore) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int pre_chunks = 2 * SEARCH_PRE_SPOTS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const int chunk = blockIdx.x / q_tiles, q0 = (blockIdx.x % q_tiles) * 128;
+    const int doc0 = ((chunk >> 1) * pre_step + pre_step - 1) * 256 + (chunk & 1) * 128;
+    gemm_acc_t acc;
+    gemm_zero(acc);
+    gemm_mainloop(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qn = q0 + wn * 64 + j * 16 + fq * 4 + r;
+            // (a lane's four rows i * 16 + fr of the 64-row block go to positions fr * 4 + i: ONE 16-byte store, 256 contiguous bytes
+            // per 16 lanes — search_thr_own_kernel undoes the permutation when it names the row)
+            float* gs = gscore + (size_t)qn * (pre_chunks * 128) + chunk * 128 + wm * 64 + fr * 4;
+            float m = -INFINITY;
+            f32x4 v4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v4[i] = doc0 + wm * 64 + i * 16 + fr < p.n_docs ? acc[i][j][r] : -INFINITY;
+                m = fmaxf(m, v4[i]);
+            }
+            *reinterpret_cast<f32x4*>(gs) = v4;
+            gmax[((size_t)qn * pre_chunks + chunk) * PRE_GROUPS + wm * 16 + fr] = m;
+        }
+    }
+}
+
+// one wave per query: threshold as in search_thr_kernel, then the query's 4096 sampled scores against it
+template <int KP>
+__global__ __launch_bounds__(256) void search_thr_own_kernel(SearchArgs p, const float* __restrict__ gmax, const float* __restrict__ gscore,
+                                                             int nq_pad, int pre_step, float* __restrict__ thr, float* __restrict__ thr_cert) {
+    constexpr int pre_chunks = 2 * SEARCH_PRE_SPOTS, NS = pre_chunks * 128, CAP = 64;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq_pad) return;
+    const float* g = gmax + (size_t)q * pre_chunks * PRE_GROUPS;
+    float m = -INFINITY;
+    for (int t = 0; t < pre_chunks * PRE_GROUPS / 64; ++t) m = fmaxf(m, g[t * 64 + lane]);
+    const uint64_t sorted = wave_sort_desc((uint64_t)f32_orderable(m) << 32);
+    const uint64_t kth = shfl_u64(sorted, KP - 1);
+    const float th = orderable_f32((uint32_t)(kth >> 32));
+    const int own_lists = p.pre_own_chunks * 2, slots = own_lists * CAP;
+    const size_t list0 = ((size_t)q * p.n_chunks + (p.n_chunks - p.pre_own_chunks)) * 2;     // first own half-list of the query
+    unsigned long long* keys = p.cand_keys + list0 * CAP;
+    int base = 0;
+    if (q < p.nq) {                                      // (padding queries: empty lists, threshold +inf in the sweep anyway)
+        const float* gs = gscore + (size_t)q * NS;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        f32x4 v[NS / 256];                               // all sixteen loads in flight at once
+#pragma unroll
+        for (int t = 0; t < NS / 256; ++t) v[t] = *reinterpret_cast<const f32x4*>(gs + t * 256 + lane * 4);
+#pragma unroll
+        for (int t = 0; t < NS / 256; ++t) {
+            const float mx = fmaxf(fmaxf(v[t][0], v[t][1]), fmaxf(v[t][2], v[t][3]));
+            if (__ballot(mx >= th && mx > -INFINITY) == 0ull) continue;      // (~18 of 4096 rows reach the threshold)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool pass = v[t][u] >= th && v[t][u] > -INFINITY;
+                const unsigned long long bal = __ballot(pass);
+                if (bal) {
+                    if (pass) {
+                        const int pos = base + __popcll(bal & lt);
+                        const int e = t * 256 + lane * 4 + u, c = e >> 7, w = e & 63;       // position fr * 4 + i of its 64-row block
+                        const int doc = ((c >> 1) * pre_step + pre_step - 1) * 256 + (c & 1) * 128 + (e & 64) + (w & 3) * 16 + (w >> 2);
+                        if (pos < slots) keys[(pos % own_lists) * CAP + pos / own_lists] = make_key(v[t][u], (uint32_t)doc);
+                    }
+                    base += __popcll(bal);
+                }
+            }
+        }
+    }
+    // (dealt round-robin over the own half-lists: the merge walks a list with ONE thread — eighteen entries in one list were a
+    // chain of five dependent cold loads behind everybody else's one, +8 us per merge)
+    if (lane < own_lists) p.cand_ids[list0 + lane] = min(CAP, (base + own_lists - 1 - lane) / own_lists);
+    if (lane == 0) {
+        thr[q] = th;
+        thr_cert[q] = base > slots ? INFINITY : th;     // overflow: rows were dropped, the lists prove nothing
+    }
+}
+
+
 // ---- merge of the sorted chunk lists (128-tile sweep, streaming kernel): one workgroup per query ----
 // 256 threads read all chunk entries with independent loads, bound the GD-th best from the chunk
 // heads (GD = KP + 16: the certification below may want candidates past the KP-th), filter, sort the
@@ -304,7 +400,7 @@ int search_kprime(int k) {
     return 0;
 }
 
-int search_prepass_floats() { return PRE_CHUNKS * PRE_GROUPS; }
+int search_prepass_floats() { return PRE_CHUNKS * PRE_GROUPS + 2 * SEARCH_PRE_SPOTS * 128; }   // group maxima + (owning form) every sampled score
 
 bool search_uses_256(int nq) {
     // 17..128 queries also run faster on the 256^2 sweep (half-empty query tile and all: 0.29 vs 0.33 ms)
@@ -333,6 +429,20 @@ int search_num_chunks(int64_t n_docs, int nq) {
 
 constexpr int SMALL_NQ = 16;        // up to here: no pre-pass, workgroup-per-query merge
 
+#ifndef VR_PREPASS_OWN
+#define VR_PREPASS_OWN 1
+#endif
+int search_prepass_owned(int64_t n_docs, int nq, int dim) {
+    const int64_t tiles = (n_docs + 255) / 256;
+    // (one tile in eight at most — as for the plain pre-pass — and the one-wave sweep's conditions: search256w.hip)
+    if (!VR_PREPASS_OWN || !search_uses_256(nq) || nq <= SMALL_NQ || dim % 128 || tiles < 8 * SEARCH_PRE_SPOTS) return 0;
+    // only where it shortens the sweep: the lists of its own cost the threshold kernel and the merge ~15 us (1k x 100k: 7 -> 6
+    // tiles per workgroup, -36 us of sweep; 256 queries x 100k: 2 tiles per workgroup either way)
+    const int c_all = search_num_chunks(n_docs, nq), c_own = search_num_chunks(n_docs - (int64_t)SEARCH_PRE_SPOTS * 256, nq);
+    const int64_t tpc_all = (tiles + c_all - 1) / c_all, tpc_own = (tiles - SEARCH_PRE_SPOTS + c_own - 1) / c_own;
+    return tpc_own < tpc_all ? 8 : 0;
+}
+
 template <int KP>
 static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     const int q_tiles = (a.nq + 127) / 128;
@@ -347,7 +457,27 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     // against the sweep — an 8-way shard of the 100k index has 98 tiles)
     int pre_chunks = PRE_CHUNKS;
     while (pre_chunks > 8 && n_tiles < 8 * pre_chunks) pre_chunks /= 2;
-    if (a.thr_init && n_tiles >= 8 * pre_chunks && a.nq > SMALL_NQ) {
+    const float* thr_cert = nullptr;
+    if (a.pre_own_chunks) {
+        // the pre-pass owns its sample (see search_prepass_own_kernel): the caller sized the lists with search_prepass_owned
+        if (!a.thr_init || !a.thr_cert || !a.cand_keys || a.pre_own_chunks != search_prepass_owned(a.n_docs, a.nq, a.dim) ||
+            a.n_chunks <= a.pre_own_chunks)
+            return hipErrorInvalidValue;
+        static unsigned long long pattr = 0;    // bit d: set on device d
+        set_max_dynamic_lds((const void*)search_prepass_own_kernel, GEMM_SMEM_BYTES, pattr);
+        const int pre_step = (int)((a.n_docs + 255) / 256) / SEARCH_PRE_SPOTS;
+        float* gmax = a.cand_scores;                                   // [nq_pad128][32][PRE_GROUPS]
+        float* gscore = gmax + (size_t)q_tiles * 128 * PRE_CHUNKS * PRE_GROUPS;    // [nq_pad128][4096]
+        static_assert(PRE_CHUNKS == 2 * SEARCH_PRE_SPOTS, "32 sampled 128-row tiles = 16 index tiles of 256 rows");
+        hipLaunchKernelGGL(search_prepass_own_kernel, dim3(PRE_CHUNKS * q_tiles), dim3(256), GEMM_SMEM_BYTES, s, a, q_tiles, pre_step,
+                           gmax, gscore);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(search_thr_own_kernel<KP>, dim3(q_tiles * 32), dim3(256), 0, s, a, (const float*)gmax, (const float*)gscore,
+                           q_tiles * 128, pre_step, a.thr_init, a.thr_cert);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        thr = a.thr_init;
+        thr_cert = a.thr_cert;
+    } else if (a.thr_init && n_tiles >= 8 * pre_chunks && a.nq > SMALL_NQ) {
         static unsigned long long pattr = 0;    // bit d: set on device d
         set_max_dynamic_lds((const void*)search_prepass_kernel, GEMM_SMEM_BYTES, pattr);
         float* gmax = a.cand_scores;                   // [nq_pad128][pre_chunks][PRE_GROUPS], dead before the sweep writes
@@ -361,7 +491,7 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
     }
     if (a.prof_ev && (e = hipEventRecord(a.prof_ev[2], s)) != hipSuccess) return e;
     SearchArgs am = a;
-    am.thr_used = thr;                                                       // what the sweep's lists are complete down to
+    am.thr_used = thr_cert ? thr_cert : thr;                                 // what the lists are complete down to
     if (search_uses_256(a.nq)) return launch_sweep256(am, KP, thr, s);      // sweep + its own merge
     if (search_uses_stream(a.nq, a.dim)) {
         if ((e = launch_search_stream(a, KP, s)) != hipSuccess) return e;

@@ -370,6 +370,7 @@ static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s)
 #define VR_SWEEP_W 1
 #endif
     hipError_t e;
+    if (a.pre_own_chunks && !(VR_SWEEP_W && sweep256w_ok(a))) return hipErrorInvalidValue;   // (only that sweep skips tiles)
     if (VR_SWEEP_W && sweep256w_ok(a)) {     // the one-wave-per-SIMD form of the sweep (search256w.hip)
         e = launch_sweep256w(a, KP, thr, s);
     } else {

@@ -74,7 +74,7 @@ __device__ __forceinline__ void* sw_uniform_ptr(const char* q) {
 
 template <int KP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, const float* __restrict__ thr_init) {
+void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, const float* __restrict__ thr_init, int pre_spots, int pre_step) {
     constexpr int NS = 64, NR = 16, DS = 5, SB1 = 40, D1 = 5, SB2 = 8;     // the schedule of gemm256w.hip, NJ = 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const thr_lds = reinterpret_cast<float*>(smem + 2 * SW_STAGE);
@@ -86,9 +86,12 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
     const int chunk = __builtin_amdgcn_readfirstlane((b / (8 * q_tiles)) * 8 + (b & 7));   // the query tiles of a chunk share an XCD
     const int qt = __builtin_amdgcn_readfirstlane((b >> 3) % q_tiles);
     const int q0 = qt * 256;
-    const int n_tiles = (int)((p.n_docs + 255) / 256);
+    // the tiles this sweep walks, numbered 0 .. n_tiles - 1: all index tiles, or (pre_spots > 0) all but the pre-pass's sampled
+    // ones — index tile k * pre_step + pre_step - 1 for k < pre_spots is scored by search_prepass_own_kernel and nobody else
+    const int n_tiles = (int)((p.n_docs + 255) / 256) - pre_spots;
     const int tile_lo = chunk * tiles_per_chunk;
     const int tile_hi = min(n_tiles, tile_lo + tiles_per_chunk);
+    auto index_tile = [&](int t) { return pre_spots > 0 ? t + min(t / (pre_step - 1), pre_spots) : t; };
     // half-list of query qq (0..255 in this tile), owner half wm: gw + qq * gq
     unsigned long long* gw = p.cand_keys + (((size_t)q0 * p.n_chunks + chunk) * 2 + wm) * SW_HL_CAP;
     const size_t gq = (size_t)p.n_chunks * 2 * SW_HL_CAP;
@@ -158,7 +161,7 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
         const unsigned tile_bytes = 256u * (unsigned)p.dim * 2u;
         // (pinned into SGPRs: a descriptor hipcc cannot prove wave-uniform gets a readfirstlane loop around every load)
         const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(
-            sw_uniform_ptr((const char*)p.index_bf16 + (size_t)tile_lo * tile_bytes), 0, 0x7FFFFFFF, 0x00020000);
+            sw_uniform_ptr((const char*)p.index_bf16 + (size_t)index_tile(tile_lo) * tile_bytes), 0, 0x7FFFFFFF, 0x00020000);
         const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(
             sw_uniform_ptr((const char*)p.q_bf16 + (size_t)q0 * p.dim * 2), 0, 0x7FFFFFFF, 0x00020000);
         const unsigned lof = (unsigned)(lane >> 3) * (unsigned)p.dim * 2u + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
@@ -197,14 +200,16 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
         }
 
         for (int tile = tile_lo; tile < tile_hi; ++tile) {
-            const unsigned curA = (unsigned)(tile - tile_lo) * tile_bytes;
+            const int itile = index_tile(tile);
+            const unsigned curA = (unsigned)(itile - index_tile(tile_lo)) * tile_bytes;
             const bool more = tile + 1 < tile_hi;
+            const unsigned nextA = (unsigned)(index_tile(tile + 1) - index_tile(tile_lo)) * tile_bytes;    // (past a skipped tile)
             auto step = [&](auto stage_c, int kt) {
                 constexpr int S = decltype(stage_c)::value;
                 const int k2 = kt + 2;
                 // step kt + 2 of this tile, or step kt + 2 - nk of the next one, or (last tile) nowhere
                 const unsigned kb = (unsigned)(k2 < nk ? k2 : k2 - nk) * (GEMM_BK * 2);
-                const unsigned vA = lof + (k2 < nk ? curA + kb : (more ? curA + tile_bytes + kb : SW_OOB));
+                const unsigned vA = lof + (k2 < nk ? curA + kb : (more ? nextA + kb : SW_OOB));
                 const unsigned vW = lof + ((k2 < nk || more) ? kb : SW_OOB);
                 __builtin_amdgcn_sched_barrier(0);
                 auto aux1 = [&](int sl) {
@@ -244,7 +249,7 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
 
             // ---- filter epilogue of this tile, strip by strip (32 accumulator registers read back at a time; no
             //      workgroup barrier).  acc n = strip * 8 + fragment: v[j][r] = score(doc strip i, query j*16 + fq*4 + r)
-            const int doc0 = tile * 256;
+            const int doc0 = itile * 256;
             const uint32_t below = (1u << fr) - 1u;
 #pragma unroll
             for (int i = 0; i < ((SW_DBG & 1) ? 0 : 8); ++i) {
@@ -312,24 +317,41 @@ void search_sweep256w_kernel(SearchArgs p, int q_tiles, int tiles_per_chunk, con
     }
 }
 
+// sweep geometry: workgroup chunks, the tiles they walk (index tiles minus the pre-pass's own), tiles per chunk
+namespace {
+struct SwGeo { int chunks, n_tiles, spots, step, tpc; size_t span_bytes; };
+SwGeo sw_geometry(const SearchArgs& a) {
+    SwGeo g{};
+    const int all = (int)((a.n_docs + 255) / 256);
+    g.spots = a.pre_own_chunks > 0 ? SEARCH_PRE_SPOTS : 0;
+    g.step = g.spots ? all / g.spots : 0;
+    g.n_tiles = all - g.spots;
+    g.chunks = a.n_chunks - a.pre_own_chunks;
+    g.tpc = g.chunks > 0 ? (g.n_tiles + g.chunks - 1) / g.chunks : 0;
+    // index tiles a chunk's 32-bit offsets may reach: its own, the next one (prefetch), the skipped ones in between
+    const int skipped = g.spots ? g.tpc / (g.step - 1) + 2 : 0;
+    g.span_bytes = (size_t)(g.tpc + 1 + skipped) * 256 * a.dim * 2;
+    return g;
+}
+}  // namespace
+
 template <int KP>
 static hipError_t launch_t(const SearchArgs& a, const float* thr, hipStream_t s) {
     const int q_tiles = (a.nq + 255) / 256;
-    const int n_tiles = (int)((a.n_docs + 255) / 256);
-    const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
-    if ((size_t)(tpc + 1) * 256 * a.dim * 2 >= (1ull << 31)) return hipErrorInvalidValue;      // 32-bit chunk offsets
+    const SwGeo g = sw_geometry(a);
+    if (g.chunks <= 0 || g.chunks % 8 || g.span_bytes >= (1ull << 31)) return hipErrorInvalidValue;      // 32-bit chunk offsets
+    if (g.spots && (g.step < 8 || !a.thr_cert)) return hipErrorInvalidValue;
     auto k = search_sweep256w_kernel<KP>;
     static unsigned long long attr = 0;     // bit d: set on device d
     set_max_dynamic_lds((const void*)k, SW_SMEM, attr);
-    hipLaunchKernelGGL(k, dim3(a.n_chunks * q_tiles), dim3(256), SW_SMEM, s, a, q_tiles, tpc, thr);
+    hipLaunchKernelGGL(k, dim3(g.chunks * q_tiles), dim3(256), SW_SMEM, s, a, q_tiles, g.tpc, thr, g.spots, g.step);
     return hipGetLastError();
 }
 
 // the sweep only (same scratch layout as launch_sweep256, whose merge kernel follows): dim % 128 == 0
 bool sweep256w_ok(const SearchArgs& a) {
-    const int n_tiles = (int)((a.n_docs + 255) / 256);
-    const int tpc = (n_tiles + a.n_chunks - 1) / a.n_chunks;
-    return a.dim % 128 == 0 && (size_t)(tpc + 1) * 256 * a.dim * 2 < (1ull << 31);
+    const SwGeo g = sw_geometry(a);
+    return a.dim % 128 == 0 && g.chunks > 0 && g.span_bytes < (1ull << 31);
 }
 hipError_t launch_sweep256w(const SearchArgs& a, int kp, const float* thr, hipStream_t s) {
     if (!a.cand_keys || a.n_chunks % 8 || !sweep256w_ok(a)) return hipErrorInvalidValue;

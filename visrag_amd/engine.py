@@ -324,6 +324,13 @@ class HipIndex:
                 "band_pass": int(out[2]) - int(out[5]), "exact_pass": int(out[5]),
                 "uncertified": int(out[3]), "regathered": int(out[4])}
 
+    def search_plan(self, nq: int) -> Dict[str, int]:
+        """How a search of `nq` queries (k <= 26) is laid out over the rows added so far (include/visrag_hip.h:
+        vr_index_search_plan): `prepass_chunks` > 0 = the threshold pre-pass owns its sampled tiles, the sweep skips them."""
+        out = (C.c_int32 * 4)()
+        _lib.check(self.lib.vr_index_search_plan(self._h, int(nq), out))
+        return {"list_chunks": int(out[0]), "prepass_chunks": int(out[1]), "sweep_chunks": int(out[2]), "tiles_per_chunk": int(out[3])}
+
     def error_model(self) -> Dict[str, float]:
         """What the default certification bound is made of (include/visrag_hip.h: vr_index_set_search_eps)."""
         out = (C.c_float * 4)()
