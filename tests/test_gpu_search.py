@@ -828,3 +828,32 @@ def test_prepass_own_lists_overflow_is_flagged_not_wrong():
     assert list(ids[0]) == [777] + rows[:9].tolist(), ids[0]
     _assert_ids_equal_fp64(ids, sc, C, Q, k)
     assert st["flagged"] >= 1 and st["uncertified"] == 0, st
+
+
+def test_streaming_search_hands_huge_bands_to_the_exact_pass_after_the_first():
+    """A handful of queries whose error band is the whole index (an error model nothing satisfies): the FIRST such search is
+    redone by the merge workgroups themselves (no launches behind the streaming search: 70 ms per query at 100 000 rows) and
+    sets the index's host-visible word; from the second search on the exact fp32 pass is launched behind the merge and takes
+    the flagged queries (~1 ms per 8 queries).  Same ids and the same floats either way; vr_index_reset clears the word."""
+    nd, nq, dim, k = 30000, 8, 2304, 10
+    C, Q = _unit(nd, dim, 91), _unit(nq, dim, 92)
+    ix = HipIndex(dim, nd); ix.add(C)
+    ix.set_search_eps(100.0)
+    ix.search_stats(reset=True)
+    sc1, ids1 = ix.search(Q, k)
+    st1 = ix.search_stats(reset=True)
+    assert st1["flagged"] == nq and st1["band_pass"] == nq and st1["exact_pass"] == 0, st1
+    sc2, ids2 = ix.search(Q, k)
+    st2 = ix.search_stats(reset=True)
+    assert st2["flagged"] == nq and st2["exact_pass"] == nq, st2
+    assert np.array_equal(ids1, ids2) and np.array_equal(sc1, sc2)
+    _assert_ids_equal_fp64(ids2, sc2, C, Q, k)
+    ix.set_search_eps(None)                                      # ordinary queries on the same index: nothing is flagged, results exact
+    sc3, ids3 = ix.search(Q, k)
+    assert np.array_equal(ids3, ids1)
+    ix.reset(); ix.add(C)
+    ix.set_search_eps(100.0)
+    ix.search_stats(reset=True)
+    ix.search(Q, k)
+    st4 = ix.search_stats()
+    assert st4["band_pass"] == nq and st4["exact_pass"] == 0, st4

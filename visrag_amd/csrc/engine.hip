@@ -1274,6 +1274,7 @@ struct vr_index_s {
     // extended re-scoring, flagged, uncertified mode, candidates gathered a second time, of the flagged: exact fp32 pass}
     DevBuf cert, flags, flagq;        // flags: int flag_list[fcap] | int flag2_list[fcap] | f32 flag_tau[fcap]; flagq: bf16 [fcap][dim]
     int64_t fcap = 0;
+    int* huge_seen = nullptr;         // pinned host word: a streaming search met a band beyond search_band_max() rows (SearchArgs::huge_seen)
     float eps_rel = -2.f;             // -2: the rigorous data-dependent default; >= 0: the caller's eps_rel |q| max|d|; else off
     // per-stage HIP events (vr_index_set_search_profile): convert | thresholds | sweep | merge | exact pass
     bool prof_on = false;
@@ -1293,7 +1294,9 @@ extern "C" int vr_index_create(int device_id, int32_t dim, int64_t capacity, vr_
     int r = ix->f32.alloc((size_t)cp * dim * 4);
     if (r == VR_OK) r = ix->bf16.alloc((size_t)cp * dim * 2);
     if (r == VR_OK) r = ix->cert.alloc(CERT_WORDS * 4);
+    if (r == VR_OK && hipHostMalloc((void**)&ix->huge_seen, 64, hipHostMallocDefault) != hipSuccess) r = fail(VR_ERR_HIP, "hipHostMalloc");
     if (r != VR_OK) { ix->f32.free(); ix->bf16.free(); ix->cert.free(); delete ix; return r; }
+    *ix->huge_seen = 0;
     *out = ix;
     return VR_OK;
 }
@@ -1306,6 +1309,7 @@ extern "C" int vr_index_destroy(vr_index_t ix) {
                       &ix->sbuf, &ix->cert, &ix->flags, &ix->flagq})
         b->free();
     for (hipEvent_t e : ix->prof_ev) if (e) (void)hipEventDestroy(e);
+    if (ix->huge_seen) (void)hipHostFree(ix->huge_seen);
     delete ix;
     return VR_OK;
 }
@@ -1316,6 +1320,7 @@ extern "C" int vr_index_reset(vr_index_t ix) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(ix->cert.p, 0, 8));          // largest row norm, largest rounding residual
     ix->n = 0;
+    if (ix->huge_seen) *ix->huge_seen = 0;
     return VR_OK;
 }
 
@@ -1472,6 +1477,11 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
             // (a handful of queries: the streaming sweep leaves every bf16 score behind — a query its merge cannot certify is
             // redone by that merge workgroup itself, and none of the fallback launches below is issued)
             if (conv_in_kernel) { a.score_rows = ix->sbuf.as<float>(); a.ld_scores = (size_t)ldS; }
+            // (... unless the band is beyond search_band_max() rows: the first such query is walked by its one workgroup and sets
+            // the host-visible word; from then on the exact pass is launched behind this index's streaming searches)
+            const bool exact_small = conv_in_kernel && ix->huge_seen && __atomic_load_n(ix->huge_seen, __ATOMIC_RELAXED) != 0;
+            a.exact_follows = exact_small ? 1 : 0;
+            a.huge_seen = ix->huge_seen;
             a.eps_data = ix->eps_rel == -2.f ? 1 : 0;
             a.eps_rel = a.eps_data ? 0.f : ix->eps_rel;
             a.acc_rel = search_acc_rel(dim);
@@ -1537,6 +1547,12 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
                                                ix->sbuf.as<float>(), (size_t)ldS, s));
                     HIPCHK(launch_exact_select(ax, ix->sbuf.as<float>(), (size_t)ldS, (int)f0, ns, s));
                 }
+            }
+            if ((a.eps_data || a.eps_rel >= 0.f) && a.score_rows && exact_small) {
+                SearchArgs ax = a;
+                ax.flag_count = a.flag2_count; ax.flag_list = a.flag2_list;
+                HIPCHK(launch_exact_scores(a.index_f32, a.n_docs, dim, a.q_f32, ax.flag_list, ax.flag_count, 0, nb, ix->sbuf.as<float>(), (size_t)ldS, s));
+                HIPCHK(launch_exact_select(ax, ix->sbuf.as<float>(), (size_t)ldS, 0, nb, s));
             }
             if (prof) {
                 HIPCHK(hipEventRecord(ix->prof_ev[5], s));

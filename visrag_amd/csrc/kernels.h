@@ -246,6 +246,10 @@ struct SearchArgs {
     float* score_rows; size_t ld_scores;               // streaming search (nq <= 16) only: the sweep writes EVERY bf16-MFMA score,
                                                        // [16][ld_scores] (ld_scores % 256 == 0, >= n_docs), and a query its merge cannot
                                                        // certify is redone in place by its own merge workgroup (search_band.h)
+    int exact_follows;               // streaming search with score_rows: 1 = the exact fp32 pass IS launched behind this merge — a query whose band
+                                     // exceeds search_band_max() rows goes on the flag2 list instead of being walked by its one workgroup
+    int* huge_seen;                  // host-visible word (or null): set when a merge workgroup had to walk such a band itself (exact_follows == 0);
+                                     // the engine launches the exact pass behind the index's streaming searches from then on
     // ---- certification of the candidate selection (search_common.h: certify_tail)
     const float* thr_used;           // thresholds the sweep STARTED from (set by the launcher; null: none)
     float eps_rel;                   // >= 0: |bf16-MFMA score - fp32 score| <= eps_rel * |q| * dmax (the caller's model);

@@ -133,6 +133,21 @@ __device__ __forceinline__ int band_pass_in_place(const SearchArgs& p, int q, fl
     uint64_t best = KEY_NONE;
     bool first = true;
     int n_band = band_gather<NT>(row, 0, n_docs, tau, L, ucnt_s);
+    if (n_band > BAND_MAX) {
+        // One workgroup re-scoring tens of thousands of fp32 rows takes milliseconds (100 000 rows: 70 ms; the exact pass sweeps
+        // the fp32 index with the whole chip: ~1 ms per 8 queries).  When the exact pass follows this launch the query goes on
+        // its list; when it does not (the common case: its two idle launches were 7 us of a 105 us search) the walk below is
+        // done once and the host-visible word makes the engine launch the exact pass behind this index's searches from now on.
+        if (p.exact_follows) {
+            if (threadIdx.x == 0) {
+                const int pos = atomicAdd(p.flag2_count, 1);
+                p.flag2_list[pos] = q;
+                if (p.stats) atomicAdd(&p.stats[5], 1u);
+            }
+            return n_band;
+        }
+        if (threadIdx.x == 0 && p.huge_seen) __hip_atomic_store(p.huge_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (n_band <= BAND_MAX) {
         band_rescore<NT>(p, qv, n_band, L);
         band_fold64<NT>(L, n_band, best, first);
