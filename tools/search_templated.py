@@ -19,7 +19,10 @@ rows = torch.empty((n_fam * per, E), device="cuda")
 for f in range(n_fam):
     r = centers[f][None, :] + t_f[f] * torch.randn((per, E), generator=g, device="cuda") / E ** 0.5
     rows[f * per:(f + 1) * per] = r / r.norm(dim=1, keepdim=True)
-Q = torch.randn((nq, E), generator=g, device="cuda") + 3.0 * centers[torch.randint(0, n_fam, (nq,), generator=g, device="cuda")]
+fam_q = torch.randint(0, n_fam, (nq,), generator=g, device="cuda")
+if os.environ.get("SORTQ") == "1":          # (experiment: queries of a family adjacent — what a locality sort of the flagged queries would give)
+    fam_q = fam_q.sort().values
+Q = torch.randn((nq, E), generator=g, device="cuda") + 3.0 * centers[fam_q]
 Q /= Q.norm(dim=1, keepdim=True)
 ix = HipIndex(E, n_fam * per); ix.add(rows)
 for _ in range(2):

@@ -39,7 +39,12 @@ __global__ __launch_bounds__(BAND_NT) void band_select_kernel(SearchArgs p, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int n_slots = min(max(p.flag_count[0] - sub, 0), max_slots);
     const int n_docs = (int)p.n_docs, k = p.k, dim = p.dim, nv = dim >> 2;
-    for (int slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
+#ifndef BAND_XCD
+#define BAND_XCD 0
+#endif
+    // (BAND_XCD: consecutive slots of a round on ONE XCD — workgroup b of the 256 takes slot (b % 8) * 32 + b / 8 of its round)
+    const int bslot = BAND_XCD && gridDim.x == 256 ? (int)(blockIdx.x & 7) * 32 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    for (int slot = bslot; slot < n_slots; slot += gridDim.x) {
         const int q = p.flag_list[sub + slot];
         const float tau = p.flag_tau[sub + slot];
         const float* row = S + (size_t)slot * ldS;
