@@ -223,13 +223,15 @@ int vr_index_error_model(vr_index_t ix, float* out4);
 /* Queries counted since the last reset: out6[0..5] = {certified at once, certified after extended
  * re-scoring, flagged (redone by the band pass), searched with certification off, of the second
  * group: those whose candidates had to be gathered a second time, of the flagged: those whose band
- * exceeded 8192 rows and went through the exact fp32 pass}. */
+ * exceeded 8192 rows — redone by the exact fp32 pass, or (the first such queries of an index: the exact
+ * pass is only launched behind an index that has shown one) walked by one workgroup}. */
 int vr_index_search_stats(vr_index_t ix, int64_t* out6, int32_t reset);
-/* How a search of `nq` queries (k <= 26) over the rows added so far would be laid out: out4 = {list chunks per query,
+/* How a search of `nq` queries (k <= 26) over the rows added so far would be laid out: out5 = {list chunks per query,
  * of them the chunks that belong to the threshold pre-pass (0, or 8 when the pre-pass OWNS its sample: its 16 sampled 256-row
  * tiles are scored once, their survivors kept in lists of their own, and the sweep skips them), workgroup chunks of the
- * sweep, index tiles (256 rows) per workgroup chunk}.  Introspection only (tests, bench.py's `search.plan`). */
-int vr_index_search_plan(vr_index_t ix, int32_t nq, int32_t* out4);
+ * sweep, index tiles (256 rows) per workgroup chunk, whether the exact fp32 pass is launched behind the search (1 once the
+ * index has met a band beyond 8192 rows; vr_index_reset clears it)}.  Introspection only (tests, bench.py's `search.plan`). */
+int vr_index_search_plan(vr_index_t ix, int32_t nq, int32_t* out5);
 /* Per-stage HIP-event times of vr_index_search (k <= 26), summed over calls since enabling:
  * ms5 = {query conversion, threshold pre-pass, sweep, merge + re-scoring, band + exact pass}.
  * While enabled every call ends with an event synchronisation. */

@@ -375,9 +375,8 @@ def test_exact_pass_alone_matches_oracle(nd, nq, dim, k):
     sc, ids = ix.search(Q, k)
     st = ix.search_stats()
     kk = min(k, nd)
-    in_place = nq <= 16 and dim % 256 == 0 and dim <= 2560       # the streaming search redoes a flagged query inside its merge workgroup,
-    if nd > k + 24:                                              # whatever the band's size (segments of 8192 rows): no exact-pass launches
-        assert st["flagged"] == nq and (st["exact_pass"] == nq if nd > 8192 and not in_place else st["band_pass"] == nq), st   # (<= 8192 rows: a band-pass round per query)
+    if nd > k + 24:                                              # (bands beyond 8192 rows: counted as exact_pass whoever walks them —
+        assert st["flagged"] == nq and (st["exact_pass"] == nq if nd > 8192 else st["band_pass"] == nq), st   # the first ones of an index: one workgroup each)
     _assert_ids_equal_fp64(ids[:, :kk], sc[:, :kk], C, Q, kk)
     if kk < k:
         assert (ids[:, kk:] == -1).all() and np.isinf(sc[:, kk:]).all()
@@ -840,9 +839,11 @@ def test_streaming_search_hands_huge_bands_to_the_exact_pass_after_the_first():
     ix = HipIndex(dim, nd); ix.add(C)
     ix.set_search_eps(100.0)
     ix.search_stats(reset=True)
+    assert ix.search_plan(nq)["exact_pass_launched"] == 0
     sc1, ids1 = ix.search(Q, k)
     st1 = ix.search_stats(reset=True)
-    assert st1["flagged"] == nq and st1["band_pass"] == nq and st1["exact_pass"] == 0, st1
+    assert st1["flagged"] == nq and st1["exact_pass"] == nq, st1
+    assert ix.search_plan(nq)["exact_pass_launched"] == 1
     sc2, ids2 = ix.search(Q, k)
     st2 = ix.search_stats(reset=True)
     assert st2["flagged"] == nq and st2["exact_pass"] == nq, st2
@@ -852,8 +853,12 @@ def test_streaming_search_hands_huge_bands_to_the_exact_pass_after_the_first():
     sc3, ids3 = ix.search(Q, k)
     assert np.array_equal(ids3, ids1)
     ix.reset(); ix.add(C)
+    assert ix.search_plan(nq)["exact_pass_launched"] == 0
+    # the sweeps behind a pre-pass likewise (band_select_kernel walks the first huge bands itself)
+    Q40 = _unit(40, dim, 93)
     ix.set_search_eps(100.0)
-    ix.search_stats(reset=True)
-    ix.search(Q, k)
-    st4 = ix.search_stats()
-    assert st4["band_pass"] == nq and st4["exact_pass"] == 0, st4
+    sc4, ids4 = ix.search(Q40, k)
+    assert ix.search_plan(40)["exact_pass_launched"] == 1
+    sc5, ids5 = ix.search(Q40, k)
+    assert np.array_equal(ids4, ids5) and np.array_equal(sc4, sc5)
+    _assert_ids_equal_fp64(ids5, sc5, C, Q40, k)

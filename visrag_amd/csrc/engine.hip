@@ -1363,7 +1363,8 @@ extern "C" int vr_index_search_stats(vr_index_t ix, int64_t* out6, int32_t reset
     return VR_OK;
 }
 
-extern "C" int vr_index_search_plan(vr_index_t ix, int32_t nq, int32_t* out4) {
+extern "C" int vr_index_search_plan(vr_index_t ix, int32_t nq, int32_t* out5) {
+    int32_t* out4 = out5;
     if (!ix || !out4 || nq <= 0) return fail(VR_ERR_INVALID, "bad arguments");
     const bool stream = search_uses_stream(nq, ix->dim);
     const int own = stream ? 0 : search_prepass_owned(ix->n, nq, ix->dim);
@@ -1371,6 +1372,7 @@ extern "C" int vr_index_search_plan(vr_index_t ix, int32_t nq, int32_t* out4) {
     const int64_t tile = search_uses_256(nq) ? 256 : 128;
     const int64_t tiles = (ix->n + tile - 1) / tile - (own ? SEARCH_PRE_SPOTS : 0);
     out4[0] = sweep + own; out4[1] = own; out4[2] = sweep; out4[3] = stream ? 0 : (int)((tiles + sweep - 1) / sweep);
+    out5[4] = (ix->huge_seen && __atomic_load_n(ix->huge_seen, __ATOMIC_RELAXED) != 0) ? 1 : 0;
     return VR_OK;
 }
 
@@ -1479,8 +1481,12 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
             if (conv_in_kernel) { a.score_rows = ix->sbuf.as<float>(); a.ld_scores = (size_t)ldS; }
             // (... unless the band is beyond search_band_max() rows: the first such query is walked by its one workgroup and sets
             // the host-visible word; from then on the exact pass is launched behind this index's streaming searches)
-            const bool exact_small = conv_in_kernel && ix->huge_seen && __atomic_load_n(ix->huge_seen, __ATOMIC_RELAXED) != 0;
-            a.exact_follows = exact_small ? 1 : 0;
+            const bool huge_seen = ix->huge_seen && __atomic_load_n(ix->huge_seen, __ATOMIC_RELAXED) != 0;
+            const bool exact_small = conv_in_kernel && huge_seen;
+            // (the sweeps behind a pre-pass likewise: band_select_kernel walks the first band beyond search_band_max() rows itself;
+            // deep retrieval, k > 26, keeps the exact pass — its select handles any k)
+            const bool exact_big = !conv_in_kernel && (bigk || huge_seen || !ix->huge_seen);
+            a.exact_follows = (exact_small || exact_big) ? 1 : 0;
             a.huge_seen = ix->huge_seen;
             a.eps_data = ix->eps_rel == -2.f ? 1 : 0;
             a.eps_rel = a.eps_data ? 0.f : ix->eps_rel;
@@ -1541,7 +1547,7 @@ static int search_impl(vr_index_t ix, const float* queries, int32_t nq, int32_t 
                 }
                 SearchArgs ax = a;
                 ax.flag_count = a.flag2_count; ax.flag_list = a.flag2_list;
-                for (int64_t f0 = 0; f0 < nb; f0 += slots) {
+                for (int64_t f0 = 0; exact_big && f0 < nb; f0 += slots) {
                     const int ns = (int)std::min<int64_t>(slots, nb - f0);
                     HIPCHK(launch_exact_scores(a.index_f32, a.n_docs, dim, a.q_f32, ax.flag_list, ax.flag_count, (int)f0, ns,
                                                ix->sbuf.as<float>(), (size_t)ldS, s));

@@ -146,7 +146,10 @@ __device__ __forceinline__ int band_pass_in_place(const SearchArgs& p, int q, fl
             }
             return n_band;
         }
-        if (threadIdx.x == 0 && p.huge_seen) __hip_atomic_store(p.huge_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            if (p.huge_seen) __hip_atomic_store(p.huge_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.stats) atomicAdd(&p.stats[5], 1u);          // (counted like the ones the exact pass takes)
+        }
     }
     if (n_band <= BAND_MAX) {
         band_rescore<NT>(p, qv, n_band, L);

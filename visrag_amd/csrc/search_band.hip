@@ -50,12 +50,20 @@ __global__ __launch_bounds__(BAND_NT) void band_select_kernel(SearchArgs p, cons
         const float* row = S + (size_t)slot * ldS;
         // ---- 1. ONE pass over the score row: the band's row ids
         const int n_band = band_gather<BAND_NT>(row, 0, n_docs, tau, L, &ucnt_s);
-        if (n_band > BAND_MAX || !(tau > -INFINITY)) {                   // workgroup-uniform: the exact fp32 pass
-            if (tid == 0) {
-                const int pos = atomicAdd(p.flag2_count, 1);
-                p.flag2_list[pos] = q;
-                if (p.stats) atomicAdd(&p.stats[5], 1u);
+        if (n_band > BAND_MAX || !(tau > -INFINITY)) {                   // workgroup-uniform: the exact fp32 pass ...
+            if (p.exact_follows || k > 64) {
+                if (tid == 0) {
+                    const int pos = atomicAdd(p.flag2_count, 1);
+                    p.flag2_list[pos] = q;
+                    if (p.stats) atomicAdd(&p.stats[5], 1u);
+                }
+                continue;
             }
+            // ... which is only launched behind an index that has shown such a band before (SearchArgs::huge_seen: its two idle
+            // launches were 7 us of every search).  The first one is walked HERE, by this workgroup, in segments of BAND_MAX
+            // rows (search_band.h: milliseconds per query), and sets the word.
+            __syncthreads();
+            band_pass_in_place<BAND_NT>(p, q, tau, row, L, &ucnt_s);
             continue;
         }
         // ---- 2. exact fp32 scores

@@ -317,7 +317,7 @@ class HipIndex:
     def search_stats(self, reset: bool = False) -> Dict[str, int]:
         """Queries since the last reset by outcome: certified from the sweep's candidates at once / after re-scoring more of
         them; `flagged` = redone behind the sweep, of which `band_pass` by re-scoring every row inside the error band and
-        `exact_pass` by the fp32 pass over the whole index; `uncertified` = searched with certification off."""
+        `exact_pass` = band beyond 8192 rows (the fp32 pass over the whole index, or — the first such queries of an index — one workgroup's walk); `uncertified` = searched with certification off."""
         out = (C.c_int64 * 6)()
         _lib.check(self.lib.vr_index_search_stats(self._h, out, 1 if reset else 0))
         return {"certified": int(out[0]), "certified_extended": int(out[1]), "flagged": int(out[2]),
@@ -327,9 +327,10 @@ class HipIndex:
     def search_plan(self, nq: int) -> Dict[str, int]:
         """How a search of `nq` queries (k <= 26) is laid out over the rows added so far (include/visrag_hip.h:
         vr_index_search_plan): `prepass_chunks` > 0 = the threshold pre-pass owns its sampled tiles, the sweep skips them."""
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 5)()
         _lib.check(self.lib.vr_index_search_plan(self._h, int(nq), out))
-        return {"list_chunks": int(out[0]), "prepass_chunks": int(out[1]), "sweep_chunks": int(out[2]), "tiles_per_chunk": int(out[3])}
+        return {"list_chunks": int(out[0]), "prepass_chunks": int(out[1]), "sweep_chunks": int(out[2]), "tiles_per_chunk": int(out[3]),
+                "exact_pass_launched": int(out[4])}
 
     def error_model(self) -> Dict[str, float]:
         """What the default certification bound is made of (include/visrag_hip.h: vr_index_set_search_eps)."""
