@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
     __shared__ uint64_t surv[MERGE_CAP], exact_w[MERGE_CAP];
     __shared__ uint64_t cand[64], exact_s[64];
     __shared__ uint64_t thr_s;
+    __shared__ f32x4 q_s[MERGE_MAXV * 64];               // the query for certify_tail's paired re-scoring (10 KiB)
     __shared__ int n_s, x_s, comp_s;
     __shared__ unsigned drop_s;
     __shared__ float tau_s;
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void search_merge256_wg_kernel(SearchArgs p) {
         dropB = fmaxf(dropB, b);
     }
     certify_tail<KP>(p, q, cand, exact_s, coverB, dropB, &tau_s, &x_s,
-                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); }, surv, exact_w);
+                     [&](float tau) { return gather((uint64_t)f32_orderable(tau) << 32); }, surv, exact_w, false, q_s);
 }
 
 template <int KP>

@@ -198,10 +198,51 @@ __device__ __forceinline__ void block_bitonic_desc(uint64_t* keys, int n, int ti
 template <int KP, typename Regather>
 __device__ __forceinline__ bool certify_tail(const SearchArgs& p, int q, const uint64_t* cand, uint64_t* exact_s,
                                              float coverB, float dropB, float* sh_tau, int* sh_x, Regather regather,
-                                             const uint64_t* surv, uint64_t* exact_w, bool defer_flag = false) {
+                                             const uint64_t* surv, uint64_t* exact_w, bool defer_flag = false, f32x4* q_s = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int nv = p.dim >> 2;
     const float* qrow = p.q_f32 + (size_t)q * p.dim;
+#ifndef VR_RESCORE_PAIRS
+#define VR_RESCORE_PAIRS 1
+#endif
+    // q_s (LDS, MERGE_MAXV * 64 float4, the 256-thread merge of the big sweeps): the bf16 top-KP is re-scored with TWO candidate
+    // rows per wave in flight — a wave has KP / 4 of these 9 KB rows to fetch, each a memory round trip — and the query read
+    // from LDS meanwhile, so that the two rows' 80 registers do not push the kernel past 128 (four workgroups per CU; with the
+    // query in registers too: 207).  Up to 512 queries only: 256 queries 55.5 -> 45.5 us per merge, but with 1 000 workgroups
+    // resident the memory system is what the merge waits for — twice the requests in flight: 69.5 -> 83 us (tools/r6/merge_pairs.sh)
+    const bool pairs = VR_RESCORE_PAIRS && q_s != nullptr && nw * 2 <= KP && gridDim.x <= 512;
+    if (pairs) {
+        if (tid < 64) exact_s[tid] = KEY_NONE;
+        for (int c = tid; c < MERGE_MAXV * 64; c += blockDim.x)
+            q_s[c] = c < nv ? reinterpret_cast<const f32x4*>(qrow)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int c = wave; c < KP; c += 2 * nw) {
+            const uint64_t k0 = cand[c], k1 = cand[c + nw];
+            const uint32_t i0 = k0 != KEY_NONE ? ~(uint32_t)k0 : 0u, i1 = k1 != KEY_NONE ? ~(uint32_t)k1 : 0u;
+            const f32x4* r0 = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)i0 * p.dim);
+            const f32x4* r1 = reinterpret_cast<const f32x4*>(p.index_f32 + (size_t)i1 * p.dim);
+            f32x4 d0[MERGE_MAXV], d1[MERGE_MAXV];
+#pragma unroll
+            for (int i = 0; i < MERGE_MAXV; ++i) {
+                const int cc = lane + i * 64;
+                d0[i] = cc < nv ? r0[cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+                d1[i] = cc < nv ? r1[cc] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);               // (all loads of both rows are out before the first fma waits for one)
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MERGE_MAXV; ++i) {
+                const int cc = lane + i * 64;
+                if (cc < nv) { const f32x4 qc = q_s[cc]; p0 = dot_chunk(qc, d0[i], p0); p1 = dot_chunk(qc, d1[i], p1); }   // dot_lane's chain
+            }
+            const float a0 = wave_sum(p0), a1 = wave_sum(p1);
+            if (lane == 0) {
+                if (k0 != KEY_NONE) exact_s[c] = make_key(a0, i0);
+                if (k1 != KEY_NONE) exact_s[c + nw] = make_key(a1, i1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     f32x4 qv[MERGE_MAXV];
     load_query_regs(qv, qrow, nv, lane);
     auto rescore = [&](int c) {                          // wave-uniform c
@@ -212,9 +253,11 @@ __device__ __forceinline__ bool certify_tail(const SearchArgs& p, int q, const u
         if (lane == 0) exact_s[c] = make_key(a, id);
     };
     auto below = [](float bound, float tau) { return bound == -INFINITY || bound < tau; };
-    if (tid < 64) exact_s[tid] = KEY_NONE;
-    __syncthreads();
-    for (int c = wave; c < KP; c += nw) rescore(c);
+    if (!pairs) {
+        if (tid < 64) exact_s[tid] = KEY_NONE;
+        __syncthreads();
+        for (int c = wave; c < KP; c += nw) rescore(c);
+    }
     __syncthreads();
     const bool certify = p.eps_data || p.eps_rel >= 0.f;
     if (wave == 0) {
