@@ -18,9 +18,6 @@
 
 namespace vr {
 
-constexpr int PE_KMAX = 1024;          // K_pad the offset table holds (3 P^2 padded to 64: P <= 18)
-constexpr int PE_SMEM = GEMM_SMEM_BYTES + PE_KMAX * 4 + 256 * 2;
-
 struct PatchArgs {
     const uint8_t* const* imgs;      // device array of n_imgs HWC uint8 images (H x W x 3)
     int H, W, P, gw, N;              // grid width, patches per image
@@ -52,35 +49,16 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs a) {
         const int py = pp / a.gw, px = pp % a.gw;
         pbase[i] = a.imgs[img] + (size_t)(py * a.P) * rowbytes + px * seg;
     }
-    // Two small tables above the GEMM stages, built once per workgroup (round 6: per K-step a thread spent ~1 100 VALU
-    // instructions on 8 runtime divisions k / seg, k % seg and 32 times (x / 255 - 0.5) / 0.5 with IEEE divisions — ten times the
-    // tile's MFMA time; 254 us per launch):
-    //   off_tab[k] = byte offset of k inside the patch's pixels, k = ky * seg + kx3 -> ky * rowbytes + kx3 (k >= Kreal: that of Kreal - 1)
-    //   cvt_tab[x] = bf16((x / 255 - 0.5) / 0.5) — the SAME float operations, once per byte value: bit-identical
-    int* const off_tab = reinterpret_cast<int*>(smem + GEMM_SMEM_BYTES);
-    uint16_t* const cvt_tab = reinterpret_cast<uint16_t*>(smem + GEMM_SMEM_BYTES + PE_KMAX * 4);
-    for (int k = tid; k < p.K; k += 256) {
-        const int kk = min(k, a.Kreal - 1);
-        off_tab[k] = (kk / seg) * rowbytes + (kk % seg);
-    }
-    {
-        const float f = ((float)tid / 255.0f - 0.5f) / 0.5f;
-        cvt_tab[tid] = __builtin_bit_cast(uint16_t, f2bf(f));
-    }
-    __syncthreads();
-    // byte e of chunk (k0 + kc*8): k = k0 + kc*8 + e
+    // byte e of chunk (k0 + kc*8): k = k0 + kc*8 + e -> image row ky = k / seg, offset k % seg
     uint8_t px8[4][8];
     auto load_pixels = [&](int k0) {
-        int off[8];
-#pragma unroll
-        for (int e = 0; e < 8; e += 4) {
-            const int4 o = *reinterpret_cast<const int4*>(&off_tab[k0 + kc * 8 + e]);
-            off[e] = o.x; off[e + 1] = o.y; off[e + 2] = o.z; off[e + 3] = o.w;
-        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            const int k = k0 + kc * 8 + e;
+            const int kk = min(k, a.Kreal - 1);
+            const int off = (kk / seg) * rowbytes + (kk % seg);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) px8[i][e] = pbase[i][off[e]];
+            for (int i = 0; i < 4; ++i) px8[i][e] = pbase[i][off];
         }
     };
     auto write_tile = [&](char* tile, int k0) {
@@ -90,8 +68,8 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs a) {
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bf16_t c = __builtin_bit_cast(bf16_t, cvt_tab[px8[i][e]]);
-                v[e] = (rok[i] && k0 + kc * 8 + e < a.Kreal) ? c : (bf16_t)0.f;
+                const float f = ((float)px8[i][e] / 255.0f - 0.5f) / 0.5f;
+                v[e] = (rok[i] && k0 + kc * 8 + e < a.Kreal) ? f2bf(f) : (bf16_t)0.f;
             }
             *reinterpret_cast<bf16x8*>(tile + row * 128 + ((kc ^ (row & 7)) << 4)) = v;
         }
@@ -123,14 +101,14 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs a) {
 hipError_t launch_patch_embed(const uint8_t* const* imgs, int n_imgs, int H, int W, int P, const GemmArgs& g, int Kreal,
                               hipStream_t s) {
     if (n_imgs <= 0) return hipSuccess;
-    if (H % P || W % P || g.N % GEMM_BN || g.K % GEMM_BK || Kreal != 3 * P * P || Kreal > g.K || g.K > PE_KMAX || g.rowmap || g.ksplit > 1)
+    if (H % P || W % P || g.N % GEMM_BN || g.K % GEMM_BK || Kreal != 3 * P * P || Kreal > g.K || g.rowmap || g.ksplit > 1)
         return hipErrorInvalidValue;
     PatchArgs a{};
     a.imgs = imgs; a.H = H; a.W = W; a.P = P; a.gw = W / P; a.N = (H / P) * (W / P); a.g = g; a.Kreal = Kreal;
     const int tiles = (g.N / GEMM_BN) * ((g.M + GEMM_BM - 1) / GEMM_BM);
     static unsigned long long attr = 0;     // bit d: set on device d
-    set_max_dynamic_lds((const void*)patch_embed_kernel, PE_SMEM, attr);
-    hipLaunchKernelGGL(patch_embed_kernel, dim3(tiles), dim3(256), PE_SMEM, s, a);
+    set_max_dynamic_lds((const void*)patch_embed_kernel, GEMM_SMEM_BYTES, attr);
+    hipLaunchKernelGGL(patch_embed_kernel, dim3(tiles), dim3(256), GEMM_SMEM_BYTES, s, a);
     return hipGetLastError();
 }
 
