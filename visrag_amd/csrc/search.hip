@@ -145,6 +145,38 @@ __global__ __launch_bounds__(256) void search_sweep_kernel(SearchArgs p, int q_t
 // the sweep's filter lets ~450 instead of ~1900 candidates per query through (1k x 100k: 0.567 ->
 // 0.536 ms with 8 -> 32 tiles, 0.547 with 64).
 constexpr int PRE_CHUNKS = 32;     // sampled 128-row tiles = 4096 rows at most (8 or 16 for small shards: one tile in eight)
+
+// The pre-pass's K loop: gemm_core.h's 128 x 128 x 64 tile with FOUR LDS stages instead of two.  The sampled index rows come
+// from HBM, cold, one workgroup per CU: with two stages (the load of step t + 1 issued when step t starts, everything drained at
+// the next barrier) a K-step was one memory round trip — 36 steps x ~1 us = 36 us for 0.28 us of MFMAs each.  Here the loads run
+// three steps ahead behind a COUNTED wait (a wave's eight 1 KiB LDS-DMA loads per step complete in order: `vmcnt(16)` = step kt
+// has landed, the two younger steps stay in flight) and a raw barrier (`__syncthreads()` would drain them: its fence waits for
+// `vmcnt(0)` while an LDS-DMA is pending).  The barrier of step kt also says every wave is done with step kt - 1: its stage is
+// the one the loads of step kt + 3 go to.
+constexpr int PRE_NST = 4;
+constexpr int PRE_SMEM_BYTES = PRE_NST * 2 * GEMM_TILE_BYTES;      // 128 KiB
+__device__ __forceinline__ void prepass_mainloop(gemm_acc_t& acc, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                 int ldw, int m0, int n0, int K, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nk = K / GEMM_BK;
+    auto stage = [&](int kt) {
+        char* st = smem + (kt % PRE_NST) * 2 * GEMM_TILE_BYTES;
+        stage_glds(A, lda, m0, kt * GEMM_BK, st, wave, lane);
+        stage_glds(W, ldw, n0, kt * GEMM_BK, st + GEMM_TILE_BYTES, wave, lane);
+    };
+    for (int t = 0; t < PRE_NST - 1 && t < nk; ++t) stage(t);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = min(PRE_NST - 1, nk - kt) - 1;             // steps behind kt that are in flight (8 loads per wave each)
+        if (younger >= 2) VR_WAIT_VM_BARRIER(16);
+        else if (younger == 1) VR_WAIT_VM_BARRIER(8);
+        else VR_WAIT_VM_BARRIER(0);
+        if (kt + PRE_NST - 1 < nk) stage(kt + PRE_NST - 1);
+        const char* cur = smem + (kt % PRE_NST) * 2 * GEMM_TILE_BYTES;
+        gemm_compute_tile(acc, cur, cur + GEMM_TILE_BYTES, wm, wn, lane);
+    }
+    __syncthreads();
+}
 constexpr int PRE_GROUPS = 32;     // group maxima per (query, tile)
 
 __global__ __launch_bounds__(256) void search_prepass_kernel(SearchArgs p, int q_tiles, int tile_step, int pre_chunks,
@@ -156,7 +188,7 @@ __global__ __launch_bounds__(256) void search_prepass_kernel(SearchArgs p, int q
     const int doc0 = chunk * tile_step * 128;
     gemm_acc_t acc;
     gemm_zero(acc);
-    gemm_mainloop(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
+    prepass_mainloop(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -206,7 +238,7 @@ __global__ __launch_bounds__(256) void search_prepass_own_kernel(SearchArgs p, i
     const int doc0 = ((chunk >> 1) * pre_step + pre_step - 1) * 256 + (chunk & 1) * 128;
     gemm_acc_t acc;
     gemm_zero(acc);
-    gemm_mainloop(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
+    prepass_mainloop(acc, (const bf16_t*)p.index_bf16, p.dim, (const bf16_t*)p.q_bf16, p.dim, doc0, q0, p.dim, smem);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -464,12 +496,12 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
             a.n_chunks <= a.pre_own_chunks)
             return hipErrorInvalidValue;
         static unsigned long long pattr = 0;    // bit d: set on device d
-        set_max_dynamic_lds((const void*)search_prepass_own_kernel, GEMM_SMEM_BYTES, pattr);
+        set_max_dynamic_lds((const void*)search_prepass_own_kernel, PRE_SMEM_BYTES, pattr);
         const int pre_step = (int)((a.n_docs + 255) / 256) / SEARCH_PRE_SPOTS;
         float* gmax = a.cand_scores;                                   // [nq_pad128][32][PRE_GROUPS]
         float* gscore = gmax + (size_t)q_tiles * 128 * PRE_CHUNKS * PRE_GROUPS;    // [nq_pad128][4096]
         static_assert(PRE_CHUNKS == 2 * SEARCH_PRE_SPOTS, "32 sampled 128-row tiles = 16 index tiles of 256 rows");
-        hipLaunchKernelGGL(search_prepass_own_kernel, dim3(PRE_CHUNKS * q_tiles), dim3(256), GEMM_SMEM_BYTES, s, a, q_tiles, pre_step,
+        hipLaunchKernelGGL(search_prepass_own_kernel, dim3(PRE_CHUNKS * q_tiles), dim3(256), PRE_SMEM_BYTES, s, a, q_tiles, pre_step,
                            gmax, gscore);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(search_thr_own_kernel<KP>, dim3(q_tiles * 32), dim3(256), 0, s, a, (const float*)gmax, (const float*)gscore,
@@ -479,9 +511,9 @@ static hipError_t launch_kp(const SearchArgs& a, hipStream_t s) {
         thr_cert = a.thr_cert;
     } else if (a.thr_init && n_tiles >= 8 * pre_chunks && a.nq > SMALL_NQ) {
         static unsigned long long pattr = 0;    // bit d: set on device d
-        set_max_dynamic_lds((const void*)search_prepass_kernel, GEMM_SMEM_BYTES, pattr);
+        set_max_dynamic_lds((const void*)search_prepass_kernel, PRE_SMEM_BYTES, pattr);
         float* gmax = a.cand_scores;                   // [nq_pad128][pre_chunks][PRE_GROUPS], dead before the sweep writes
-        hipLaunchKernelGGL(search_prepass_kernel, dim3(pre_chunks * q_tiles), dim3(256), GEMM_SMEM_BYTES, s, a, q_tiles,
+        hipLaunchKernelGGL(search_prepass_kernel, dim3(pre_chunks * q_tiles), dim3(256), PRE_SMEM_BYTES, s, a, q_tiles,
                            n_tiles / pre_chunks, pre_chunks, gmax);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(search_thr_kernel<KP>, dim3(q_tiles * 32), dim3(256), 0, s, (const float*)gmax, q_tiles * 128,
