@@ -807,6 +807,11 @@ def test_prepass_that_owns_its_sample(nd, nq, dim, k):
     assert st["uncertified"] == 0 and st["certified"] + st["certified_extended"] + st["flagged"] == nq, st
     assert st["flagged"] <= nq // 50, st                       # random rows: the lists prove the result, nothing behind the sweep
     assert ix.search_plan(16)["prepass_chunks"] == 0 and ix.search_plan(1)["prepass_chunks"] == 0
+    # the packed-key output of the multi-GPU exchange takes the same route (a 2-way shard of the 100k index is such a shape)
+    from visrag_amd.retriever import unpack_keys_host
+    keys = ix.search_keys(torch.from_numpy(Q).cuda(), k, id_offset=11)
+    us, ui = unpack_keys_host(keys.cpu().numpy())
+    assert np.array_equal(ui, ids + 11) and np.array_equal(us, sc)
 
 
 def test_prepass_own_lists_overflow_is_flagged_not_wrong():
