@@ -237,7 +237,8 @@ def sharded_search(index, queries, k: int, id_offset: int = 0, group=None,
     same `queries` [nq, dim] (a cuda tensor; a cpu tensor or numpy array is moved to the index's device).
     Returns the global (scores, ids) [nq, k] on every rank.
 
-    The data path is three library calls and one collective, no tensor arithmetic in between:
+    A world of one rank (no process group, or a group of one) with the library's own calls is ONE call, `index.search`.
+    Otherwise the data path is three library calls and one collective, no tensor arithmetic in between:
       1. `index.search_keys(queries, k, id_offset)` — the local fused search, whose merge kernel writes
          each result as ONE 64-bit word, orderable(score) << 32 | ~global_id (vr_index_search_keys);
       2. ONE `all_gather_into_tensor` of those [nq, k] words (80 KB per rank at nq = 1000, k = 10;
@@ -267,6 +268,13 @@ def sharded_search(index, queries, k: int, id_offset: int = 0, group=None,
     if local_search_keys is None and index is not None and not (isinstance(queries, torch.Tensor) and queries.is_cuda):
         queries = torch.as_tensor(np.ascontiguousarray(queries, dtype=np.float32) if not isinstance(queries, torch.Tensor)
                                   else queries).to(f"cuda:{index.device}")      # host queries: the exchange buffer lives in HBM
+    if local_search_keys is None and merge_keys is None and index is not None and not _collective_wanted(group):
+        # a world of ONE rank with the library's own calls: nothing to exchange, so no exchange format either — the local search
+        # writes (scores, ids) itself (one launch and two allocations less per search than pack -> merge of a single part)
+        sc, ids = index.search(queries, k)
+        if id_offset:
+            ids += int(id_offset) * (ids >= 0)
+        return sc, ids
     keys = (local_search_keys or index.search_keys)(queries, k, id_offset)
     if not isinstance(keys, torch.Tensor):
         keys = torch.from_numpy(np.ascontiguousarray(keys))
