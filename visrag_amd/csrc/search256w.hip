@@ -16,9 +16,10 @@
 // filter epilogue the MFMA stream resumes at once.  Index rows come from HBM (each is read once per
 // chunk and shared by the query tiles of the chunk through the XCD's L2); search256.hip's touch-ahead of
 // step s + 3 measured -7 % here (a wave's loads complete in order, so the touch has one K-step to land
-// and the K-step is now 1.1 us).  Per tile (1000 queries x 100k rows): K-loop 39 us, filter epilogue
-// 17 us with the 1024-row threshold pre-pass — ~1900 candidates per query pass it — and about half
-// that with the 4096-row pre-pass now in search.hip.
+// and the K-step is now 1.1 us).  Per tile (1000 queries x 100k rows): K-loop 44-48 us, filter epilogue 12 us with the
+// 4096-row pre-pass and a compare -> ballot -> branch per value, 8 us with the sign-mask form below (round 6).
+// Round 6 also: when the threshold pre-pass OWNS its sampled tiles (SearchArgs::pre_own_chunks, search.hip) this sweep
+// walks the OTHER index tiles only — 375 instead of 391 at 100k rows: six per workgroup instead of seven.
 //
 // Half-list of query qq, owner half wm: [query][chunk][wm][64] keys, as in search256.hip; a wave now
 // owns the half-lists of 128 queries (32 byte-counters per lane in 8 registers).

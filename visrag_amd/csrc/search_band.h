@@ -4,6 +4,7 @@
 // the streaming sweep has every score in registers anyway and writes them out (6.4 MB next to the 460 MB it reads), so a
 // flagged query of that path is redone by ITS OWN merge workgroup: no band GEMM, no selection launch, no exact-pass launches —
 // the four launches that used to follow every search and leave at once (11.6 us of a 117 us single query) are gone.
+// (A band beyond BAND_MAX rows is the exception: see band_pass_in_place — walked here once, the exact pass from then on.)
 #pragma once
 #include "kernels.h"
 #include "search_common.h"
