@@ -269,7 +269,16 @@ __global__ __launch_bounds__(256) void search_thr_own_kernel(SearchArgs p, const
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq_pad) return;
     const float* g = gmax + (size_t)q * pre_chunks * PRE_GROUPS;
+    // the query's 4096 scores are requested FIRST: they do not depend on the threshold, and the fold + sort below then run under
+    // their latency instead of in front of it (one memory round trip per wave instead of two)
+    f32x4 v[NS / 256];
+    {
+        const float* gs = gscore + (size_t)q * NS;
+#pragma unroll
+        for (int t = 0; t < NS / 256; ++t) v[t] = *reinterpret_cast<const f32x4*>(gs + t * 256 + lane * 4);
+    }
     float m = -INFINITY;
+#pragma unroll
     for (int t = 0; t < pre_chunks * PRE_GROUPS / 64; ++t) m = fmaxf(m, g[t * 64 + lane]);
     const uint64_t sorted = wave_sort_desc((uint64_t)f32_orderable(m) << 32);
     const uint64_t kth = shfl_u64(sorted, KP - 1);
@@ -279,11 +288,7 @@ __global__ __launch_bounds__(256) void search_thr_own_kernel(SearchArgs p, const
     unsigned long long* keys = p.cand_keys + list0 * CAP;
     int base = 0;
     if (q < p.nq) {                                      // (padding queries: empty lists, threshold +inf in the sweep anyway)
-        const float* gs = gscore + (size_t)q * NS;
         const unsigned long long lt = (1ull << lane) - 1ull;
-        f32x4 v[NS / 256];                               // all sixteen loads in flight at once
-#pragma unroll
-        for (int t = 0; t < NS / 256; ++t) v[t] = *reinterpret_cast<const f32x4*>(gs + t * 256 + lane * 4);
 #pragma unroll
         for (int t = 0; t < NS / 256; ++t) {
             const float mx = fmaxf(fmaxf(v[t][0], v[t][1]), fmaxf(v[t][2], v[t][3]));
